@@ -1,0 +1,170 @@
+/*
+ * mofa_hip.h -- C ABI of libmofa_hip.so, the MI355X (gfx950) kernels behind the
+ * MOFA-Video denoising hot path.
+ *
+ * The reference (MyNiuuu/MOFA-Video) has no C/FFI boundary of its own: its only native
+ * code is three CUDA kernels held as Python strings and JIT-launched through CuPy with raw
+ * device pointers + the torch stream (MOFA-Video-Traj/models/softsplat.py:219-226,
+ * :341-345); everything else dispatches through torch/diffusers.  This header is the
+ * boundary a maintainer binds instead -- same calling discipline as that CuPy launch:
+ * plain device pointers, sizes, and the caller's stream.  No torch types, no allocation
+ * inside the library, no global state.  Every entry point returns 0 on success or a
+ * negative MOFA_E* code; kernels are enqueued on `stream` and nothing synchronises.
+ *
+ * Layout convention: activations are fp16 "token-major" (NHWC): a tensor
+ * [frames, H, W, C] is a row-major matrix of frames*H*W rows by C channels, row stride
+ * `ld*` in elements.  Weights are fp16 [N][K] with K contiguous (conv: K = taps*Cin,
+ * tap-major).  Small per-channel vectors (bias, norm affine, row vectors) are fp32.
+ *
+ * Each entry point cites the reference interface it replaces (file:line under
+ * /root/reference/MOFA-Video-Traj unless noted; "diffusers" = diffusers==0.24.0, the
+ * reference's pinned third-party dependency that holds the block arithmetic).
+ */
+#ifndef MOFA_HIP_H
+#define MOFA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mofa_stream_t; /* hipStream_t */
+
+#define MOFA_OK 0
+#define MOFA_EINVAL (-22)
+#define MOFA_ELAUNCH (-5)
+
+/* library version / build probe */
+int mofa_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM on MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate).
+ *   out[m, n] = act( s_acc * (sum_{tap,k} X[src(m,tap), k] * W[n, tap*Cin + k] + bias[n] + rowvec[idx(m), n])
+ *                    + s1 * R1[m, n] + s2 * R2[m, n] )
+ * Replaces every nn.Linear / nn.Conv2d(1x1, 3x3 s1/s2, nearest-2x + 3x3) / nn.Conv3d((3,1,1))
+ * the reference reaches through diffusers blocks (ResnetBlock2D, TemporalResnetBlock,
+ * Downsample2D, Upsample2D, Attention.to_q/k/v/out, FeedForward; built at
+ * models/unet_spatio_temporal_condition_controlnet.py:169-232, models/controlnet_sdv.py:259-309)
+ * and the adapter's own convs (models/svdxt_featureflow_forward_controlnet_s2d_fixcmp_norefine.py:66-155).
+ * ---------------------------------------------------------------------------------------- */
+enum { MOFA_MODE_PLAIN = 0, MOFA_MODE_CONV3X3 = 1, MOFA_MODE_CONVT3 = 2 };
+enum { MOFA_ACT_NONE = 0, MOFA_ACT_SILU = 1, MOFA_ACT_GEGLU_PAIR = 2 };
+
+typedef struct mofa_igemm_args {
+    const void* x;      /* fp16 activations                                                  */
+    const void* w;      /* fp16 weights [N][taps*Cin]                                        */
+    const float* bias;  /* fp32 [N] or NULL                                                  */
+    const float* rowvec;/* fp32 [nvec][N] or NULL; idx(m) = ((m / rv_div) * rv_mul + (m % rv_mod_in)) % rv_mod_out */
+    const void* r1;     /* fp16 residual [M][ldr1] or NULL                                   */
+    const void* r2;     /* fp16 residual [M][ldr2] or NULL                                   */
+    void* out;          /* fp16 [M][ldo]  (N columns; N/2 for MOFA_ACT_GEGLU_PAIR)           */
+    int32_t M, N, Cin;  /* Cin % 64 == 0, N % 4 == 0                                         */
+    int32_t ldx, ldo, ldr1, ldr2;
+    int32_t mode;       /* MOFA_MODE_*                                                       */
+    /* MOFA_MODE_CONV3X3: rows are (img, oy, ox); pad 1; stride 1|2; up = 1|2 (nearest)      */
+    int32_t Hin, Win, Hout, Wout, stride, up;
+    /* MOFA_MODE_CONVT3: rows are (frame, pixel); frames grouped in clips of T               */
+    int32_t T, HW;
+    int32_t rv_div, rv_mul, rv_mod_in, rv_mod_out;
+    int32_t act;        /* MOFA_ACT_*                                                        */
+    float s_acc, s1, s2;
+} mofa_igemm_args;
+
+int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention.  q/k/v are column blocks of token-major matrices: element (token, head, d) at
+ * base[token*ld + head*64 + d].  Replaces diffusers AttnProcessor2_0 / F.scaled_dot_product_attention
+ * inside BasicTransformerBlock.attn1 (spatial) and TemporalBasicTransformerBlock.attn1 (temporal).
+ * ---------------------------------------------------------------------------------------- */
+/* spatial self-attention, head_dim 64: batch = nframes, sequence = S tokens per frame.
+ * vt is V transposed per (frame, head): vt[((frame*heads + head)*64 + d)*S + key]. */
+int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out,
+                          int nframes, int heads, int S, int ldq, int ldk, int ldo, float scale,
+                          mofa_stream_t stream);
+/* [tokens][ld] column block (head-major, 64 wide) -> vt layout above */
+int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int heads, int S, int ldv, mofa_stream_t stream);
+/* temporal self-attention over T frames per (clip, pixel, head), head_dim 64, T <= 32.
+ * token row of (clip b, frame t, pixel p) = (b*T + t)*HW + p. */
+int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out,
+                           int nclips, int T, int HW, int heads, int ld, int ldo, float scale,
+                           mofa_stream_t stream);
+/* in-place row softmax of an fp16 [rows][cols] matrix (VAE mid-block attention, 1 head x 512) */
+int mofa_softmax_rows_f16(void* x, int rows, int cols, int ld, mofa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Normalisation.  GroupNorm(32) over token-major data; statistics either per frame (2-D
+ * ResnetBlock2D / transformer norm) or per clip of T frames (TemporalResnetBlock: stats span
+ * T*H*W).  Three launches: partial sums -> finalize to per-(frame,channel) scale/shift -> apply.
+ * Replaces nn.GroupNorm + SiLU in diffusers ResnetBlock2D / TemporalResnetBlock /
+ * TransformerSpatioTemporalModel.norm / conv_norm_out (unet_..._controlnet.py:236).
+ * ---------------------------------------------------------------------------------------- */
+/* workspace `part`: fp32 [nframes][nparts][32][2], nparts = mofa_gn_nparts(HW, C) */
+int mofa_gn_nparts(int HW, int C);
+int mofa_gn_partial_f16(const void* x, float* part, int nframes, int HW, int C, int ldx, mofa_stream_t stream);
+/* frames_per_stat = 1 (spatial) or T (temporal); writes scale/shift fp32 [nframes][C] */
+int mofa_gn_finalize(const float* part, const float* gamma, const float* beta, float* scale, float* shift,
+                     int nframes, int HW, int C, int frames_per_stat, float eps, mofa_stream_t stream);
+/* y = x*scale[frame][c] + shift[frame][c]; optional SiLU */
+int mofa_affine_act_f16(const void* x, const float* scale, const float* shift, void* y,
+                        int nframes, int HW, int C, int ldx, int ldy, int silu, mofa_stream_t stream);
+/* LayerNorm over C per token (eps, affine); optional pre-add of rowvec[(m / rv_div) % rv_mod][C] */
+int mofa_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int M, int C,
+                       int ldx, int ldy, float eps, const float* rowvec, int rv_div, int rv_mod,
+                       mofa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise / data movement
+ * ---------------------------------------------------------------------------------------- */
+/* y[m][c] = a * x[m][c] + b * y[m][c]  (fp16 storage, fp32 math); C % 8 == 0 */
+int mofa_axpby_f16(const void* x, void* y, int M, int C, int ldx, int ldy, float a, float b, mofa_stream_t stream);
+/* out[m][j] = x[m][j] * gelu(x[m][Ch + j]), j < Ch  (diffusers GEGLU, erf gelu) */
+int mofa_geglu_f16(const void* x, void* out, int M, int Ch, int ldx, int ldo, mofa_stream_t stream);
+/* strided 2-D copy of a column block: dst[m][0..C) = src[m][0..C); C % 8 == 0 */
+int mofa_copy2d_f16(const void* src, void* dst, int M, int C, int lds, int ldd, mofa_stream_t stream);
+/* y = silu(x) on fp32 vectors (time-embedding non-linearity) */
+int mofa_silu_f32(const float* x, float* y, int n, mofa_stream_t stream);
+/* fp32 -> fp16 / fp16 -> fp32 contiguous casts */
+int mofa_cast_f32_to_f16(const float* x, void* y, int64_t n, mofa_stream_t stream);
+int mofa_cast_f16_to_f32(const void* x, float* y, int64_t n, mofa_stream_t stream);
+/* NCHW fp32 [n][C][H][W] -> token-major fp16 [n][H*W][ldo] (channels >= C left untouched) and back */
+int mofa_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int C, int HW, int ldo, mofa_stream_t stream);
+int mofa_nhwc_f16_to_nchw_f32(const void* x, float* y, int n, int C, int HW, int ldx, mofa_stream_t stream);
+/* sinusoidal Timesteps(dim, flip_sin_to_cos=True, shift=0): out fp32 [n][dim]  (diffusers embeddings.py) */
+int mofa_timestep_embedding(const float* t, float* out, int n, int dim, mofa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MOFA-Adapter warp: softsplat(tenIn, tenFlow, None, 'avg')  (models/softsplat.py:232-274 +
+ * kernel softsplat_out :284-345).  Deterministic gather form, fused normalisation.
+ *   feat : fp16 token-major [HW][ldf]      (first-frame feature, one image)
+ *   flow : fp32 [nflows][2][H][W]          (flow frame 0 -> frame i+1 at feature resolution)
+ *   out  : fp16 token-major [nflows][HW][ldo]
+ *   ws   : int32/fp32 workspace, mofa_softsplat_ws_bytes(nflows, H, W) bytes
+ * mofa_softsplat_scatter_f32 is the atomicAdd form of the reference kernel on NCHW fp32
+ * (same op order class as the CUDA kernel; used for parity classing and as a bench baseline).
+ * ---------------------------------------------------------------------------------------- */
+int64_t mofa_softsplat_ws_bytes(int nflows, int H, int W);
+int mofa_softsplat_avg_f16(const void* feat, const float* flow, void* out, void* ws,
+                           int nflows, int H, int W, int C, int ldf, int ldo, mofa_stream_t stream);
+int mofa_softsplat_scatter_f32(const float* in, const float* flow, float* out_sum, int N, int C, int H, int W,
+                               mofa_stream_t stream);
+/* F.interpolate(flow, scale_factor=1/s) (nearest) / s  (svdxt_..._norefine.py:302-309): fp32 [n][2][H][W] -> [n][2][H/s][W/s] */
+int mofa_flow_downscale_f32(const float* flow, float* out, int n, int H, int W, int s, mofa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scheduler math (pipeline/pipeline.py:449-452, :495-500; utils/scheduling_euler_discrete_karras_fix.py:264-288, :418-528)
+ * ---------------------------------------------------------------------------------------- */
+/* model input: out[2][T][HW][ldo] fp16: cols 0..3 = latents/sqrt(sigma^2+1) (both CFG halves),
+ * cols 4..7 = image_latents[half] ; latents fp32 [T][4][HW] (NCHW), image_latents fp32 [2][4][HW] */
+int mofa_prepare_model_input(const float* latents, const float* image_latents, void* out,
+                             int T, int HW, int ldo, float sigma, mofa_stream_t stream);
+/* CFG + v-prediction Euler step, fp32 latents in place.
+ * noise_pred fp16 token-major [2][T][HW][ldn] (uncond first), g_f = gmin + (gmax-gmin)*f/(T-1) */
+int mofa_cfg_euler_step(float* latents, const void* noise_pred, int T, int HW, int ldn,
+                        float sigma, float sigma_next, float gmin, float gmax, mofa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOFA_HIP_H */

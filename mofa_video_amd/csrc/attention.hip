@@ -1,0 +1,384 @@
+// Attention kernels for gfx950 (head_dim 64).
+//
+// mofa_attn_spatial_f16: flash-style self-attention over the S = h*w tokens of one frame.
+//   One workgroup = 4 waves = 128 query rows of one (frame, head); K and V^T tiles of 64 keys are
+//   staged through double-buffered LDS.  Scores are computed TRANSPOSED (S^T = K . Q^T, MFMA
+//   32x32x16 f16) so every lane owns one query row: the softmax statistics are per-lane scalars
+//   (one cross-half exchange per tile) and the probabilities are already laid out as the B operand of
+//   O^T += V^T . P^T -- the k-slot -> key permutation of that MFMA is chosen to match the accumulator
+//   layout of S^T, so P never leaves registers.  fp32 accumulation, online softmax in exp2 domain.
+//
+// mofa_attn_temporal_f16: self-attention over the T <= 32 frames of one (clip, pixel, head); HBM-bound,
+//   one wave per sequence, VALU fp32.
+#include "common.h"
+
+#define ATT_KSTR 72   // K tile row stride (halves): 144 B, conflict-free ds_read_b128
+#define ATT_VSTR 68   // V^T tile row stride (halves): 136 B, conflict-free ds_read_b64
+#define ATT_TILE 64
+
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                              const f16* __restrict__ vt, f16* __restrict__ out,
+                                                              int heads, int S, int ldq, int ldk, int ldo, float c) {
+    __shared__ __attribute__((aligned(16))) f16 sK[2][ATT_TILE * ATT_KSTR];
+    __shared__ __attribute__((aligned(16))) f16 sV[2][ATT_TILE * ATT_VSTR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, frame = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+
+    const f16* kbase = k + (size_t)frame * S * ldk + head * 64;
+    const f16* vbase = vt + ((size_t)(frame * heads + head) * 64) * S;
+
+    // Q fragments (B operand of S^T): lane (query l31, half lh) holds Q[q][16*kk + 8*lh .. +8)
+    f16x8 qf[4];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const int qi = q0 + l31;
+        const f16* qp = q + ((size_t)frame * S + (qi < S ? qi : 0)) * ldq + head * 64 + lh * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) qf[kk] = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
+    }
+
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    // loader mapping: 64 rows x 8 chunks(16 B) per tile, 2 chunks per thread
+    const int lcol = tid & 7, lrow = tid >> 3;
+    f16x8 gk[2], gv[2];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = lrow + 32 * i;
+            const int key = k0 + row;
+            gk[i] = (key < S) ? *(const f16x8*)(kbase + (size_t)key * ldk + lcol * 8) : zero8;
+            const int kc = k0 + lcol * 8;  // V^T: row = d, 8 consecutive keys
+            gv[i] = (kc < S) ? *(const f16x8*)(vbase + (size_t)row * S + kc) : zero8;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = lrow + 32 * i;
+            *(f16x8*)&sK[buf][row * ATT_KSTR + lcol * 8] = gk[i];
+            f16x4 lo = {gv[i][0], gv[i][1], gv[i][2], gv[i][3]};
+            f16x4 hi = {gv[i][4], gv[i][5], gv[i][6], gv[i][7]};
+            *(f16x4*)&sV[buf][row * ATT_VSTR + lcol * 8] = lo;
+            *(f16x4*)&sV[buf][row * ATT_VSTR + lcol * 8 + 4] = hi;
+        }
+    };
+
+    const int ntiles = (S + ATT_TILE - 1) / ATT_TILE;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const int k0 = t * ATT_TILE;
+        if (t + 1 < ntiles) load_tile(k0 + ATT_TILE);
+
+        // ---- S^T tiles: s[ts][r] = score(key = k0 + 32*ts + (r&3) + 8*(r>>2) + 4*lh, query = l31) ----
+        f32x16 s[2];
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[ts][r] = 0.f;
+            const f16* kp = &sK[buf][(ts * 32 + l31) * ATT_KSTR + lh * 8];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const f16x8 kf = *(const f16x8*)(kp + kk * 16);
+                s[ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[ts], 0, 0, 0);
+            }
+        }
+        // ---- mask + online softmax (per-lane query row; the two halves hold disjoint key subsets) ----
+        float mx = -1e30f;
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + ts * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= S) s[ts][r] = -1e30f;
+                mx = fmaxf(mx, s[ts][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float psum = 0.f;
+        f16x8 pf[2][2];
+#pragma unroll
+        for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(fmaf(s[ts][r], c, -mc));
+                psum += p;
+                pf[ts][r >> 3][r & 7] = (f16)p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+
+        // ---- O^T[d][q] += V^T[d][key] * P^T[key][q]; k-slot (8*lh + jj) of MFMA (ts,u) = key
+        //      32*ts + 16*u + 4*lh + (jj&3) + 8*(jj>>2), identical for both operands ---------------
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const f16* vp = &sV[buf][(db * 32 + l31) * ATT_VSTR + 4 * lh];
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const f16x4 lo = *(const f16x4*)(vp + ts * 32 + u * 16);
+                    const f16x4 hi = *(const f16x4*)(vp + ts * 32 + u * 16 + 8);
+                    const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ts][u], o[db], 0, 0, 0);
+                }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int qi = q0 + l31;
+    if (qi < S) {
+        f16* op = out + ((size_t)frame * S + qi) * ldo + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                f16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][4 * qd + e] * inv);
+                *(f16x4*)(op + db * 32 + 8 * qd + 4 * lh) = v;
+            }
+    }
+}
+
+extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out, int nframes, int heads,
+                                     int S, int ldq, int ldk, int ldo, float scale, mofa_stream_t stream) {
+    if (!q || !k || !vt || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
+    if (S % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
+    dim3 grid(cdiv(S, 128), heads, nframes);
+    const float c = scale * 1.4426950408889634f;
+    hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)q, (const f16*)k,
+                       (const f16*)vt, (f16*)out, heads, S, ldq, ldk, ldo, c);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// V [tokens][ldv] column block (head*64 + d) -> V^T [(frame*heads + head)*64 + d][S]
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_v_kernel(const f16* __restrict__ v, f16* __restrict__ vt, int heads,
+                                                          int S, int ldv) {
+    __shared__ f16 s[64][66];
+    const int tid = threadIdx.x;
+    const int k0 = blockIdx.x * 64, head = blockIdx.y, frame = blockIdx.z;
+    {
+        const int key = tid >> 2, dc = (tid & 3) * 16;
+        if (k0 + key < S) {
+            const f16* p = v + ((size_t)frame * S + k0 + key) * ldv + head * 64 + dc;
+            const f16x8 a = *(const f16x8*)p, b = *(const f16x8*)(p + 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[dc + e][key] = a[e]; s[dc + 8 + e][key] = b[e]; }
+        }
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 2, kc = (tid & 3) * 16;
+        f16* p = vt + ((size_t)(frame * heads + head) * 64 + d) * S + k0 + kc;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (k0 + kc + half * 8 < S) {
+                f16x8 a;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[e] = s[d][kc + half * 8 + e];
+                *(f16x8*)(p + half * 8) = a;
+            }
+        }
+    }
+}
+
+extern "C" int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int heads, int S, int ldv,
+                                    mofa_stream_t stream) {
+    if (!v || !vt || nframes <= 0 || heads <= 0 || S <= 0 || S % 8 != 0 || ldv % 8 != 0) return MOFA_EINVAL;
+    dim3 grid(cdiv(S, 64), heads, nframes);
+    hipLaunchKernelGGL(transpose_v_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)v, (f16*)vt, heads, S,
+                       ldv);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Temporal attention: sequence = the T frames of one (clip, pixel, head).  One wave per sequence:
+// lane (i = lane&31, hf = lane>>5): query i, keys [16*hf, 16*hf+16), output dims [32*hf, 32*hf+32).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                            const f16* __restrict__ v, f16* __restrict__ out,
+                                                            long long nseq, int T, int HW, int heads, int ld, int ldo,
+                                                            float scale) {
+    __shared__ __attribute__((aligned(16))) f16 sK[4][32 * 64];
+    __shared__ __attribute__((aligned(16))) f16 sV[4][32 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long seq = (long long)blockIdx.x * 4 + wave;
+    const bool active = seq < nseq;
+    const int i = lane & 31, hf = lane >> 5;
+
+    size_t base = 0;
+    if (active) {
+        const int head = (int)(seq % heads);
+        const long long bp = seq / heads;
+        const int p = (int)(bp % HW);
+        const int b = (int)(bp / HW);
+        base = ((size_t)b * T * HW + p);
+        base = base * (size_t)1;  // row of frame 0
+        // stage K and V rows of the T frames: T*8 chunks of 16 B each
+        for (int c = lane; c < T * 8; c += 64) {
+            const int t = c >> 3, cc = c & 7;
+            const size_t row = base + (size_t)t * HW;
+            *(f16x8*)&sK[wave][t * 64 + cc * 8] = *(const f16x8*)(k + row * ld + head * 64 + cc * 8);
+            *(f16x8*)&sV[wave][t * 64 + cc * 8] = *(const f16x8*)(v + row * ld + head * 64 + cc * 8);
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const int head = (int)(seq % heads);
+
+    float qv[64];
+    if (i < T) {
+        const f16* qp = q + (base + (size_t)i * HW) * ld + head * 64;
+#pragma unroll
+        for (int cidx = 0; cidx < 8; ++cidx) {
+            const f16x8 a = *(const f16x8*)(qp + cidx * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qv[cidx * 8 + e] = (float)a[e] * scale;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 64; ++e) qv[e] = 0.f;
+    }
+    float sc[16];
+    float mx = -1e30f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = hf * 16 + jj;
+        float acc = 0.f;
+        if (j < T) {
+            const f16* kp = &sK[wave][j * 64];
+#pragma unroll
+            for (int cidx = 0; cidx < 8; ++cidx) {
+                const f16x8 a = *(const f16x8*)(kp + cidx * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc = fmaf(qv[cidx * 8 + e], (float)a[e], acc);
+            }
+        } else {
+            acc = -1e30f;
+        }
+        sc[jj] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        sc[jj] = __expf(sc[jj] - mx);
+        sum += sc[jj];
+    }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+
+    float ov[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) ov[e] = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const float other = __shfl_xor(sc[jj], 32, 64);
+        const float p_lo = hf == 0 ? sc[jj] : other;   // key jj
+        const float p_hi = hf == 0 ? other : sc[jj];   // key 16 + jj
+        if (jj < T) {
+            const f16* vp = &sV[wave][jj * 64 + hf * 32];
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const f16x8 a = *(const f16x8*)(vp + cidx * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[cidx * 8 + e] = fmaf(p_lo, (float)a[e], ov[cidx * 8 + e]);
+            }
+        }
+        if (16 + jj < T) {
+            const f16* vp = &sV[wave][(16 + jj) * 64 + hf * 32];
+#pragma unroll
+            for (int cidx = 0; cidx < 4; ++cidx) {
+                const f16x8 a = *(const f16x8*)(vp + cidx * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[cidx * 8 + e] = fmaf(p_hi, (float)a[e], ov[cidx * 8 + e]);
+            }
+        }
+    }
+    if (i < T) {
+        f16* op = out + (base + (size_t)i * HW) * ldo + head * 64 + hf * 32;
+#pragma unroll
+        for (int cidx = 0; cidx < 4; ++cidx) {
+            f16x8 a;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = (f16)(ov[cidx * 8 + e] * inv);
+            *(f16x8*)(op + cidx * 8) = a;
+        }
+    }
+}
+
+extern "C" int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out, int nclips, int T, int HW,
+                                      int heads, int ld, int ldo, float scale, mofa_stream_t stream) {
+    if (!q || !k || !v || !out || nclips <= 0 || T <= 0 || T > 32 || HW <= 0 || heads <= 0) return MOFA_EINVAL;
+    if (ld % 8 != 0 || ldo % 8 != 0) return MOFA_EINVAL;
+    const long long nseq = (long long)nclips * HW * heads;
+    hipLaunchKernelGGL(attn_temporal_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
+                       (const f16*)k, (const f16*)v, (f16*)out, nseq, T, HW, heads, ld, ldo, scale);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// In-place row softmax (VAE mid-block attention: 1 head x 512, scores materialised per frame)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(f16* __restrict__ x, int cols, int ld) {
+    __shared__ float red[8];
+    f16* row = x + (size_t)blockIdx.x * ld;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mx = -1e30f;
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        const f16x8 a = *(const f16x8*)(row + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)a[e]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        const f16x8 a = *(const f16x8*)(row + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __expf((float)a[e] - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int c = tid * 8; c < cols; c += 256 * 8) {
+        f16x8 a = *(const f16x8*)(row + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (f16)(__expf((float)a[e] - mx) * inv);
+        *(f16x8*)(row + c) = a;
+    }
+}
+
+extern "C" int mofa_softmax_rows_f16(void* x, int rows, int cols, int ld, mofa_stream_t stream) {
+    if (!x || rows <= 0 || cols <= 0 || cols % 8 != 0 || ld % 8 != 0) return MOFA_EINVAL;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, (f16*)x, cols, ld);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}

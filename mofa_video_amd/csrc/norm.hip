@@ -1,0 +1,243 @@
+// GroupNorm(32) / LayerNorm for token-major fp16 activations (HBM-bound kernels).
+//
+// GroupNorm is three launches:
+//   1. gn_partial : per (frame, row-chunk, 256-channel block) fp32 sum / sum-of-squares per group
+//   2. gn_finalize: combine partials (per frame, or per clip of T frames for TemporalResnetBlock whose
+//                   statistics span T*H*W) -> per-(frame, channel) scale = rstd*gamma, shift = beta - mean*scale
+//   3. affine_act : y = x*scale + shift, optional SiLU
+// Deterministic (no float atomics across workgroups).
+#include "common.h"
+
+#define GN_MAX_CHUNKS 128
+
+static inline int gn_nchunks(int HW) {
+    int n = cdiv(HW, 256);
+    return n > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : n;
+}
+extern "C" int mofa_gn_nparts(int HW, int C) { return gn_nchunks(HW) * cdiv(C, 256); }
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x, float* __restrict__ part, int HW,
+                                                         int C, int ldx, int rows_per_chunk, int nparts) {
+    __shared__ float sS[8][256];
+    __shared__ float sQ[8][256];
+    __shared__ float gS[32], gQ[32];
+    const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
+    const int chunk = blockIdx.x, cblk = blockIdx.y, frame = blockIdx.z;
+    const int c0 = cblk * 256 + cx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    if (c0 < C) {
+        const int r0 = chunk * rows_per_chunk;
+        int r1 = r0 + rows_per_chunk;
+        r1 = r1 < HW ? r1 : HW;
+        const f16* base = x + (size_t)frame * HW * ldx + c0;
+        for (int r = r0 + ry; r < r1; r += 8) {
+            const f16x8 a = *(const f16x8*)(base + (size_t)r * ldx);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = (float)a[e];
+                s[e] += v;
+                q[e] = fmaf(v, v, q[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sS[ry][cx * 8 + e] = s[e]; sQ[ry][cx * 8 + e] = q[e]; }
+    if (tid < 32) { gS[tid] = 0.f; gQ[tid] = 0.f; }
+    __syncthreads();
+    float ts = 0.f, tq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { ts += sS[r][tid]; tq += sQ[r][tid]; }
+    // channel -> group.  Done by ONE thread per group in channel order (deterministic).
+    sS[0][tid] = ts;
+    sQ[0][tid] = tq;
+    __syncthreads();
+    if (tid < 32) {
+        const int cpg = C / 32;
+        const int g = tid;
+        int ca = g * cpg - cblk * 256, cb = ca + cpg;
+        ca = ca < 0 ? 0 : ca;
+        cb = cb > 256 ? 256 : cb;
+        float a = 0.f, b = 0.f;
+        for (int c = ca; c < cb; ++c) { a += sS[0][c]; b += sQ[0][c]; }
+        float* p = part + (((size_t)frame * nparts + (chunk * gridDim.y + cblk)) * 32 + g) * 2;
+        p[0] = a;
+        p[1] = b;
+    }
+}
+
+extern "C" int mofa_gn_partial_f16(const void* x, float* part, int nframes, int HW, int C, int ldx,
+                                   mofa_stream_t stream) {
+    if (!x || !part || nframes <= 0 || HW <= 0 || C <= 0 || C % 32 != 0 || C % 8 != 0 || ldx % 8 != 0) return MOFA_EINVAL;
+    const int nch = gn_nchunks(HW);
+    int rpc = cdiv(HW, nch);
+    rpc = (rpc + 7) / 8 * 8;
+    const int ncb = cdiv(C, 256);
+    dim3 grid(nch, ncb, nframes);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, part, HW, C, ldx, rpc,
+                       nch * ncb);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift, int HW, int C, int fps, int nparts,
+                                                          float eps) {
+    __shared__ double dS[8][32], dQ[8][32];
+    __shared__ float sMean[32], sRstd[32];
+    const int tid = threadIdx.x, g = tid & 31, l8 = tid >> 5;
+    const int stat = blockIdx.x;  // one statistics set = fps consecutive frames
+    const int total = fps * nparts;
+    double a = 0.0, b = 0.0;
+    const float* p0 = part + (size_t)stat * fps * nparts * 64;
+    for (int i = l8; i < total; i += 8) {
+        a += (double)p0[(size_t)i * 64 + g * 2];
+        b += (double)p0[(size_t)i * 64 + g * 2 + 1];
+    }
+    dS[l8][g] = a;
+    dQ[l8][g] = b;
+    __syncthreads();
+    if (tid < 32) {
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < 8; ++r) { s += dS[r][tid]; q += dQ[r][tid]; }
+        const double cnt = (double)fps * (double)HW * (double)(C / 32);
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        sMean[tid] = (float)mean;
+        sRstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / 32;
+    for (int idx = tid; idx < fps * C; idx += 256) {
+        const int f = idx / C, c = idx - f * C;
+        const int gg = c / cpg;
+        const float sc = sRstd[gg] * gamma[c];
+        const size_t o = ((size_t)stat * fps + f) * C + c;
+        scale[o] = sc;
+        shift[o] = beta[c] - sMean[gg] * sc;
+    }
+}
+
+extern "C" int mofa_gn_finalize(const float* part, const float* gamma, const float* beta, float* scale, float* shift,
+                                int nframes, int HW, int C, int frames_per_stat, float eps, mofa_stream_t stream) {
+    if (!part || !gamma || !beta || !scale || !shift || nframes <= 0 || frames_per_stat <= 0 ||
+        nframes % frames_per_stat != 0 || C % 32 != 0)
+        return MOFA_EINVAL;
+    const int nparts = mofa_gn_nparts(HW, C);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nframes / frames_per_stat), dim3(256), 0, (hipStream_t)stream, part,
+                       gamma, beta, scale, shift, HW, C, frames_per_stat, nparts, eps);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+__global__ __launch_bounds__(256) void affine_act_kernel(const f16* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, f16* __restrict__ y,
+                                                         long long nvec, int HW, int C, int ldx, int ldy, int silu) {
+    const int CV = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long row = i / CV;
+        const int cv = (int)(i - row * CV);
+        const int frame = (int)(row / HW);
+        const f16x8 a = *(const f16x8*)(x + (size_t)row * ldx + cv * 8);
+        const float* sp = scale + (size_t)frame * C + cv * 8;
+        const float* hp = shift + (size_t)frame * C + cv * 8;
+        const f32x4 s0 = *(const f32x4*)sp, s1 = *(const f32x4*)(sp + 4);
+        const f32x4 h0 = *(const f32x4*)hp, h1 = *(const f32x4*)(hp + 4);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = fmaf((float)a[e], e < 4 ? s0[e] : s1[e - 4], e < 4 ? h0[e] : h1[e - 4]);
+            if (silu) v = silu_f(v);
+            o[e] = (f16)v;
+        }
+        *(f16x8*)(y + (size_t)row * ldy + cv * 8) = o;
+    }
+}
+
+extern "C" int mofa_affine_act_f16(const void* x, const float* scale, const float* shift, void* y, int nframes, int HW,
+                                   int C, int ldx, int ldy, int silu, mofa_stream_t stream) {
+    if (!x || !scale || !shift || !y || nframes <= 0 || HW <= 0 || C % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0)
+        return MOFA_EINVAL;
+    const long long nvec = (long long)nframes * HW * (C / 8);
+    long long nb = (nvec + 255) / 256;
+    nb = nb > 16384 ? 16384 : nb;
+    hipLaunchKernelGGL(affine_act_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const f16*)x, scale, shift,
+                       (f16*)y, nvec, HW, C, ldx, ldy, silu);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// LayerNorm: one wave per token row, row held in registers (C <= 2048).
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, f16* __restrict__ y, int M,
+                                                        int C, int ldx, int ldy, float eps,
+                                                        const float* __restrict__ rowvec, int rv_div, int rv_mod) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= M) return;
+    const int CV = C >> 3;
+    float v[4][8];
+    const f16* xp = x + (size_t)row * ldx;
+    const float* rv = rowvec ? rowvec + (size_t)((row / rv_div) % rv_mod) * C : nullptr;
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int cv = lane + 64 * it;
+        if (cv < CV) {
+            const f16x8 a = *(const f16x8*)(xp + cv * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (float)a[e];
+                if (rv) t += rv[cv * 8 + e];
+                v[it][e] = t;
+                sum += t;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+        }
+    }
+    sum = wave_sum(sum);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int cv = lane + 64 * it;
+        if (cv < CV) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[it][e] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    }
+    sq = wave_sum(sq);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+    f16* yp = y + (size_t)row * ldy;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int cv = lane + 64 * it;
+        if (cv < CV) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                o[e] = (f16)fmaf((v[it][e] - mean) * rstd, gamma[cv * 8 + e], beta[cv * 8 + e]);
+            *(f16x8*)(yp + cv * 8) = o;
+        }
+    }
+}
+
+extern "C" int mofa_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, int ldx,
+                                  int ldy, float eps, const float* rowvec, int rv_div, int rv_mod,
+                                  mofa_stream_t stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || C <= 0 || C % 8 != 0 || C > 2048 || ldx % 8 != 0 || ldy % 8 != 0)
+        return MOFA_EINVAL;
+    if (rowvec && (rv_div <= 0 || rv_mod <= 0)) return MOFA_EINVAL;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma, beta,
+                       (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}

@@ -1,0 +1,106 @@
+"""ctypes binding of libmofa_hip.so (C ABI declared in include/mofa_hip.h).
+
+Same calling discipline as the reference's CuPy launch of its softsplat kernel
+(MOFA-Video-Traj/models/softsplat.py:341-345): raw device pointers from
+``tensor.data_ptr()`` and the caller's torch stream.  There is NO fallback: a
+missing library raises at import of this module's ``load()``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmofa_hip.so")
+
+MODE_PLAIN, MODE_CONV3X3, MODE_CONVT3 = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU_PAIR = 0, 1, 2
+
+
+class IgemmArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+        ("r1", C.c_void_p), ("r2", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("Cin", C.c_int32),
+        ("ldx", C.c_int32), ("ldo", C.c_int32), ("ldr1", C.c_int32), ("ldr2", C.c_int32),
+        ("mode", C.c_int32),
+        ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("stride", C.c_int32), ("up", C.c_int32),
+        ("T", C.c_int32), ("HW", C.c_int32),
+        ("rv_div", C.c_int32), ("rv_mul", C.c_int32), ("rv_mod_in", C.c_int32), ("rv_mod_out", C.c_int32),
+        ("act", C.c_int32),
+        ("s_acc", C.c_float), ("s1", C.c_float), ("s2", C.c_float),
+    ]
+
+
+_P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes (every symbol include/mofa_hip.h declares; tests check they all resolve)
+PROTOTYPES = {
+    "mofa_version": [],
+    "mofa_igemm_f16": [C.POINTER(IgemmArgs), _P],
+    "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_softmax_rows_f16": [_P, _I, _I, _I, _P],
+    "mofa_gn_nparts": [_I, _I],
+    "mofa_gn_partial_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_gn_finalize": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "mofa_affine_act_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mofa_layernorm_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
+    "mofa_axpby_f16": [_P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "mofa_geglu_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_copy2d_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_silu_f32": [_P, _P, _I, _P],
+    "mofa_cast_f32_to_f16": [_P, _P, _L, _P],
+    "mofa_cast_f16_to_f32": [_P, _P, _L, _P],
+    "mofa_nchw_f32_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_nhwc_f16_to_nchw_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_timestep_embedding": [_P, _P, _I, _I, _P],
+    "mofa_softsplat_ws_bytes": [_I, _I, _I],
+    "mofa_softsplat_avg_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mofa_softsplat_scatter_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "mofa_flow_downscale_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_prepare_model_input": [_P, _P, _P, _I, _I, _I, _F, _P],
+    "mofa_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+}
+_RESTYPE = {"mofa_softsplat_ws_bytes": C.c_int64}
+
+_lib = None
+
+
+class MofaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libmofa_hip.so; raises if it has not been built (no CPU/torch fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MofaHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). mofa_video_amd has no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MofaHipError(f"{what} failed with code {rc}")

@@ -1,0 +1,308 @@
+"""Tensor-level wrappers over the C ABI (include/mofa_hip.h).
+
+Activations are 2-D fp16 CUDA tensors, token-major: rows = frames*H*W tokens, columns =
+channels, ``stride(1) == 1`` and ``stride(0)`` = leading dimension (column-sliced views are
+fine).  PyTorch only provides device memory and the stream here; all arithmetic runs in
+libmofa_hip.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+F16 = torch.float16
+F32 = torch.float32
+
+
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "token-major 2-D tensor with unit channel stride expected"
+    return t.stride(0)
+
+
+def _chk(t, dtype):
+    assert t.is_cuda and t.dtype == dtype, f"expected cuda {dtype}, got {t.device} {t.dtype}"
+
+
+class ConvGeom:
+    """Geometry of an implicit-GEMM launch."""
+    __slots__ = ("mode", "Hin", "Win", "Hout", "Wout", "stride", "up", "T", "HW")
+
+    def __init__(self, mode=L.MODE_PLAIN, Hin=0, Win=0, Hout=0, Wout=0, stride=1, up=1, T=0, HW=0):
+        self.mode, self.Hin, self.Win, self.Hout, self.Wout = mode, Hin, Win, Hout, Wout
+        self.stride, self.up, self.T, self.HW = stride, up, T, HW
+
+
+PLAIN = ConvGeom()
+
+
+def conv3x3_geom(H, W, stride=1, up=1):
+    Hv, Wv = H * up, W * up
+    Ho = (Hv - 1) // stride + 1
+    Wo = (Wv - 1) // stride + 1
+    return ConvGeom(L.MODE_CONV3X3, H, W, Ho, Wo, stride, up)
+
+
+def convt3_geom(T, HW):
+    return ConvGeom(L.MODE_CONVT3, T=T, HW=HW)
+
+
+def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, r2=None, s2=1.0,
+          act=L.ACT_NONE, s_acc=1.0, out=None):
+    """out[m,n] = act(s_acc*(conv/gemm + bias + rowvec[idx(m)]) + s1*r1 + s2*r2).  See include/mofa_hip.h."""
+    lib = L.load()
+    _chk(x, F16); _chk(w, F16)
+    N, Ktot = w.shape
+    assert w.is_contiguous()
+    taps = {L.MODE_PLAIN: 1, L.MODE_CONV3X3: 9, L.MODE_CONVT3: 3}[geom.mode]
+    Cin = Ktot // taps
+    assert Cin * taps == Ktot and x.shape[1] >= Cin, (x.shape, w.shape, taps)
+    if M is None:
+        if geom.mode == L.MODE_CONV3X3:
+            nimg = x.shape[0] // (geom.Hin * geom.Win)
+            assert nimg * geom.Hin * geom.Win == x.shape[0]
+            M = nimg * geom.Hout * geom.Wout
+        else:
+            M = x.shape[0]
+    n_out = N // 2 if act == L.ACT_GEGLU_PAIR else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=F16, device=x.device)
+    _chk(out, F16)
+    assert out.shape[0] == M and out.shape[1] >= n_out
+    a = L.IgemmArgs()
+    a.x, a.w, a.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.rowvec = rowvec.data_ptr() if rowvec is not None else None
+    a.r1 = r1.data_ptr() if r1 is not None else None
+    a.r2 = r2.data_ptr() if r2 is not None else None
+    if bias is not None:
+        _chk(bias, F32); assert bias.numel() == N
+    if rowvec is not None:
+        _chk(rowvec, F32); assert rowvec.dim() == 2 and rowvec.shape[1] == N and rowvec.is_contiguous()
+    a.M, a.N, a.Cin = M, N, Cin
+    a.ldx, a.ldo = _ld(x), _ld(out)
+    a.ldr1 = _ld(r1) if r1 is not None else 0
+    a.ldr2 = _ld(r2) if r2 is not None else 0
+    if r1 is not None:
+        _chk(r1, F16); assert r1.shape[0] == M
+    if r2 is not None:
+        _chk(r2, F16); assert r2.shape[0] == M
+    a.mode = geom.mode
+    a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up = geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up
+    a.T, a.HW = geom.T, geom.HW
+    a.rv_div, a.rv_mul, a.rv_mod_in, a.rv_mod_out = rv
+    a.act = act
+    a.s_acc, a.s1, a.s2 = s_acc, s1, s2
+    L.check(lib.mofa_igemm_f16(C.byref(a), L.stream_ptr()), "mofa_igemm_f16")
+    return out
+
+
+# ---- normalisation -------------------------------------------------------------------------------------
+def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None):
+    lib = L.load()
+    _chk(x, F16)
+    Cc = C_ if C_ is not None else x.shape[1]
+    assert x.shape[0] == nframes * HW
+    nparts = lib.mofa_gn_nparts(HW, Cc)
+    part = torch.empty((nframes, nparts, 32, 2), dtype=F32, device=x.device)
+    scale = torch.empty((nframes, Cc), dtype=F32, device=x.device)
+    shift = torch.empty((nframes, Cc), dtype=F32, device=x.device)
+    st = L.stream_ptr()
+    L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part), nframes, HW, Cc, _ld(x), st), "mofa_gn_partial_f16")
+    L.check(lib.mofa_gn_finalize(L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes, HW, Cc,
+                                 frames_per_stat, eps, st), "mofa_gn_finalize")
+    if out is None:
+        out = torch.empty((x.shape[0], Cc), dtype=F16, device=x.device)
+    L.check(lib.mofa_affine_act_f16(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), nframes, HW, Cc, _ld(x), _ld(out),
+                                    1 if silu else 0, st), "mofa_affine_act_f16")
+    return out
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=None):
+    lib = L.load()
+    _chk(x, F16)
+    M, Cc = x.shape
+    if out is None:
+        out = torch.empty((M, Cc), dtype=F16, device=x.device)
+    L.check(lib.mofa_layernorm_f16(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(out), M, Cc, _ld(x), _ld(out), eps,
+                                   L.ptr(rowvec), rv_div, rv_mod, L.stream_ptr()), "mofa_layernorm_f16")
+    return out
+
+
+# ---- attention -----------------------------------------------------------------------------------------
+def attn_spatial(q, k, v, nframes, heads, S, scale=0.125, out=None):
+    """q/k/v: [nframes*S, heads*64] column blocks (views allowed)."""
+    lib = L.load()
+    Cc = heads * 64
+    st = L.stream_ptr()
+    vt = torch.empty((nframes * heads * 64, S), dtype=F16, device=q.device)
+    L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, heads, S, _ld(v), st), "mofa_transpose_v_f16")
+    if out is None:
+        out = torch.empty((nframes * S, Cc), dtype=F16, device=q.device)
+    L.check(lib.mofa_attn_spatial_f16(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(out), nframes, heads, S, _ld(q), _ld(k),
+                                      _ld(out), scale, st), "mofa_attn_spatial_f16")
+    return out
+
+
+def attn_temporal(q, k, v, nclips, T, HW, heads, scale=0.125, out=None):
+    lib = L.load()
+    assert _ld(q) == _ld(k) == _ld(v)
+    if out is None:
+        out = torch.empty((nclips * T * HW, heads * 64), dtype=F16, device=q.device)
+    L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, T, HW, heads, _ld(q), _ld(out),
+                                       scale, L.stream_ptr()), "mofa_attn_temporal_f16")
+    return out
+
+
+def softmax_rows_(x):
+    lib = L.load()
+    L.check(lib.mofa_softmax_rows_f16(L.ptr(x), x.shape[0], x.shape[1], _ld(x), L.stream_ptr()), "mofa_softmax_rows_f16")
+    return x
+
+
+def transpose_v(v, nframes, heads, S):
+    lib = L.load()
+    vt = torch.empty((nframes * heads * 64, S), dtype=F16, device=v.device)
+    L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, heads, S, _ld(v), L.stream_ptr()),
+            "mofa_transpose_v_f16")
+    return vt
+
+
+# ---- element-wise ---------------------------------------------------------------------------------------
+def axpby_(x, y, a=1.0, b=1.0):
+    """y = a*x + b*y (in place on y)."""
+    lib = L.load()
+    assert x.shape == y.shape
+    L.check(lib.mofa_axpby_f16(L.ptr(x), L.ptr(y), x.shape[0], x.shape[1], _ld(x), _ld(y), a, b, L.stream_ptr()),
+            "mofa_axpby_f16")
+    return y
+
+
+def geglu(x, out=None):
+    lib = L.load()
+    M, C2 = x.shape
+    Ch = C2 // 2
+    if out is None:
+        out = torch.empty((M, Ch), dtype=F16, device=x.device)
+    L.check(lib.mofa_geglu_f16(L.ptr(x), L.ptr(out), M, Ch, _ld(x), _ld(out), L.stream_ptr()), "mofa_geglu_f16")
+    return out
+
+
+def copy2d(src, dst):
+    lib = L.load()
+    assert src.shape == dst.shape
+    L.check(lib.mofa_copy2d_f16(L.ptr(src), L.ptr(dst), src.shape[0], src.shape[1], _ld(src), _ld(dst), L.stream_ptr()),
+            "mofa_copy2d_f16")
+    return dst
+
+
+def concat_channels(a, b):
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=F16, device=a.device)
+    copy2d(a, out[:, :a.shape[1]])
+    copy2d(b, out[:, a.shape[1]:])
+    return out
+
+
+def silu_f32(x):
+    lib = L.load()
+    y = torch.empty_like(x)
+    L.check(lib.mofa_silu_f32(L.ptr(x), L.ptr(y), x.numel(), L.stream_ptr()), "mofa_silu_f32")
+    return y
+
+
+def cast_f32_to_f16(x):
+    lib = L.load()
+    _chk(x, F32)
+    y = torch.empty(x.shape, dtype=F16, device=x.device)
+    L.check(lib.mofa_cast_f32_to_f16(L.ptr(x.contiguous()), L.ptr(y), x.numel(), L.stream_ptr()), "mofa_cast_f32_to_f16")
+    return y
+
+
+def cast_f16_to_f32(x):
+    lib = L.load()
+    _chk(x, F16)
+    assert x.is_contiguous()
+    y = torch.empty(x.shape, dtype=F32, device=x.device)
+    L.check(lib.mofa_cast_f16_to_f32(L.ptr(x), L.ptr(y), x.numel(), L.stream_ptr()), "mofa_cast_f16_to_f32")
+    return y
+
+
+def nchw_to_tokens(x, ld=None):
+    """fp32 [n,C,H,W] -> fp16 token-major [n*H*W, ld] (zero-padded channels when ld > C)."""
+    lib = L.load()
+    _chk(x, F32)
+    n, Cc, H, W = x.shape
+    ld = ld or Cc
+    y = (torch.zeros if ld > Cc else torch.empty)((n * H * W, ld), dtype=F16, device=x.device)
+    L.check(lib.mofa_nchw_f32_to_nhwc_f16(L.ptr(x.contiguous()), L.ptr(y), n, Cc, H * W, ld, L.stream_ptr()),
+            "mofa_nchw_f32_to_nhwc_f16")
+    return y
+
+
+def tokens_to_nchw(x, n, Cc, H, W):
+    lib = L.load()
+    _chk(x, F16)
+    y = torch.empty((n, Cc, H, W), dtype=F32, device=x.device)
+    L.check(lib.mofa_nhwc_f16_to_nchw_f32(L.ptr(x), L.ptr(y), n, Cc, H * W, _ld(x), L.stream_ptr()),
+            "mofa_nhwc_f16_to_nchw_f32")
+    return y
+
+
+def timestep_embedding(t, dim):
+    lib = L.load()
+    _chk(t, F32)
+    out = torch.empty((t.numel(), dim), dtype=F32, device=t.device)
+    L.check(lib.mofa_timestep_embedding(L.ptr(t), L.ptr(out), t.numel(), dim, L.stream_ptr()), "mofa_timestep_embedding")
+    return out
+
+
+# ---- adapter warp ------------------------------------------------------------------------------------------
+def softsplat_avg_tokens(feat, flow, H, W):
+    """feat fp16 [H*W, C] token-major (one image); flow fp32 [nflows,2,H,W] -> fp16 [nflows*H*W, C]."""
+    lib = L.load()
+    _chk(feat, F16); _chk(flow, F32)
+    nflows = flow.shape[0]
+    Cc = feat.shape[1]
+    ws = torch.empty((lib.mofa_softsplat_ws_bytes(nflows, H, W),), dtype=torch.uint8, device=feat.device)
+    out = torch.empty((nflows * H * W, Cc), dtype=F16, device=feat.device)
+    L.check(lib.mofa_softsplat_avg_f16(L.ptr(feat), L.ptr(flow.contiguous()), L.ptr(out), L.ptr(ws), nflows, H, W, Cc,
+                                       _ld(feat), _ld(out), L.stream_ptr()), "mofa_softsplat_avg_f16")
+    return out
+
+
+def softsplat_scatter_f32(tenIn, tenFlow):
+    lib = L.load()
+    _chk(tenIn, F32); _chk(tenFlow, F32)
+    N, Cc, H, W = tenIn.shape
+    out = torch.zeros_like(tenIn)
+    L.check(lib.mofa_softsplat_scatter_f32(L.ptr(tenIn.contiguous()), L.ptr(tenFlow.contiguous()), L.ptr(out), N, Cc, H,
+                                           W, L.stream_ptr()), "mofa_softsplat_scatter_f32")
+    return out
+
+
+def flow_downscale(flow, s):
+    lib = L.load()
+    _chk(flow, F32)
+    n, two, H, W = flow.shape
+    assert two == 2
+    out = torch.empty((n, 2, H // s, W // s), dtype=F32, device=flow.device)
+    L.check(lib.mofa_flow_downscale_f32(L.ptr(flow.contiguous()), L.ptr(out), n, H, W, s, L.stream_ptr()),
+            "mofa_flow_downscale_f32")
+    return out
+
+
+# ---- scheduler math ----------------------------------------------------------------------------------------
+def prepare_model_input(latents, image_latents, out, sigma):
+    lib = L.load()
+    T, four, h, w = latents.shape
+    L.check(lib.mofa_prepare_model_input(L.ptr(latents), L.ptr(image_latents), L.ptr(out), T, h * w, _ld(out),
+                                         float(sigma), L.stream_ptr()), "mofa_prepare_model_input")
+    return out
+
+
+def cfg_euler_step_(latents, noise_pred, sigma, sigma_next, gmin, gmax):
+    lib = L.load()
+    T, four, h, w = latents.shape
+    L.check(lib.mofa_cfg_euler_step(L.ptr(latents), L.ptr(noise_pred), T, h * w, _ld(noise_pred), float(sigma),
+                                    float(sigma_next), float(gmin), float(gmax), L.stream_ptr()), "mofa_cfg_euler_step")
+    return latents

@@ -1,0 +1,325 @@
+"""GPU parity tests of every kernel behind the C ABI against plain fp32 PyTorch references (floating-point
+kernels) and the CPU oracle (softsplat, scheduler math).  Inputs are seeded, asymmetric random data so a
+transposed MFMA fragment or output layout cannot pass.
+
+Tolerances (stated): fp16 storage, fp32 accumulate -> |err| <= 2e-3 * max|ref| + 2e-3 * |ref| per element
+for GEMM-class kernels; 4e-3 for attention (P is rounded to fp16 before P.V).
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _close(out, ref, tol=2e-3, what=""):
+    out = out.float().cpu()
+    ref = ref.float().cpu()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    scale = ref.abs().max().item() + 1e-12
+    err = (out - ref).abs()
+    bound = tol * scale + tol * ref.abs()
+    bad = (err > bound)
+    assert not bad.any(), (f"{what}: {bad.sum().item()} / {bad.numel()} elements out of tolerance; "
+                           f"max err {err.max().item():.4e} (scale {scale:.4e}) at {err.argmax().item()}")
+
+
+def _h(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mofa_video_amd import ops as o
+    from mofa_video_amd import lib
+    lib.load()
+    return o
+
+
+# ---------------------------------------------------------------------------------------------------------
+# implicit GEMM
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(300, 320, 192), (128, 128, 64), (1000, 4, 320), (77, 2560, 128)])
+def test_igemm_plain_epilogue(ops, M, N, K):
+    x, w = _h(M, K, seed=1), _h(N, K, seed=2, scale=0.1)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    rowvec = torch.randn(5, N, generator=torch.Generator().manual_seed(4))
+    r1, r2 = _h(M, N, seed=5), _h(M, N, seed=6)
+    rv = (7, 3, 4, 5)  # idx = ((m/7)*3 + m%4) % 5
+    out = ops.igemm(x.to(DEV), w.to(DEV), bias.to(DEV), rowvec=rowvec.to(DEV), rv=rv, r1=r1.to(DEV), s1=0.5,
+                    r2=r2.to(DEV), s2=-1.25, s_acc=0.75)
+    m = torch.arange(M)
+    idx = ((m // 7) * 3 + m % 4) % 5
+    ref = 0.75 * (x.float() @ w.float().t() + bias + rowvec[idx]) + 0.5 * r1.float() - 1.25 * r2.float()
+    _close(out, ref, what="igemm plain")
+
+
+def test_igemm_identity_asymmetric(ops):
+    """A = I check with asymmetric B (guide rule: catches row/col swapped fragments)."""
+    K = 128
+    x = torch.eye(K).half()
+    w = (torch.arange(K * K, dtype=torch.float32).reshape(K, K) % 251 / 251.0 - 0.3).half()  # w[n][k]
+    out = ops.igemm(x.to(DEV), w.to(DEV))
+    _close(out, w.float().t(), tol=1e-3, what="igemm identity")
+
+
+def test_igemm_silu_and_strided_views(ops):
+    M, N, K = 260, 192, 128
+    xbig = _h(M, K + 64, seed=7)
+    w = _h(N, K, seed=8, scale=0.1)
+    outbig = torch.zeros(M, N + 64, dtype=torch.float16, device=DEV)
+    ops.igemm(xbig.to(DEV)[:, 64:], w.to(DEV), act=1, out=outbig[:, 64:])
+    ref = F.silu(xbig[:, 64:].float() @ w.float().t())
+    _close(outbig[:, 64:], ref, what="igemm silu strided")
+    assert outbig[:, :64].abs().max().item() == 0.0
+
+
+def test_igemm_geglu_pair(ops):
+    from mofa_video_amd.weights import interleave_geglu
+    M, Cc = 200, 64
+    x = _h(M, Cc, seed=9)
+    w = _h(8 * Cc, Cc, seed=10, scale=0.2)
+    b = torch.randn(8 * Cc, generator=torch.Generator().manual_seed(11))
+    wi, bi = interleave_geglu(w, b)
+    out = ops.igemm(x.to(DEV), wi.to(DEV).contiguous(), bi.to(DEV), act=2)
+    h = x.float() @ w.float().t() + b
+    ref = h[:, :4 * Cc] * F.gelu(h[:, 4 * Cc:])
+    _close(out, ref, what="igemm geglu pair")
+
+
+@pytest.mark.parametrize("stride,up,H,W", [(1, 1, 9, 13), (2, 1, 10, 14), (1, 2, 5, 7), (2, 1, 9, 13)])
+def test_igemm_conv3x3(ops, stride, up, H, W):
+    from mofa_video_amd.weights import pack_conv3x3
+    n, Cin, Cout = 3, 64, 96
+    x = _h(n, Cin, H, W, seed=12)
+    w = _h(Cout, Cin, 3, 3, seed=13, scale=0.05)
+    b = torch.randn(Cout, generator=torch.Generator().manual_seed(14))
+    xt = x.permute(0, 2, 3, 1).reshape(n * H * W, Cin).contiguous()
+    geom = ops.conv3x3_geom(H, W, stride=stride, up=up)
+    out = ops.igemm(xt.to(DEV), pack_conv3x3(w).to(DEV), b.to(DEV), geom=geom)
+    xi = x.float()
+    if up == 2:
+        xi = F.interpolate(xi, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xi, w.float(), b, stride=stride, padding=1)
+    assert (geom.Hout, geom.Wout) == tuple(ref.shape[2:])
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    _close(out, ref, what=f"conv3x3 s{stride} up{up}")
+
+
+def test_igemm_convt3(ops):
+    from mofa_video_amd.weights import pack_conv3d_t3
+    B, T, HW, Cc = 2, 5, 33, 64
+    x = _h(B, Cc, T, HW, 1, seed=15)
+    w = _h(Cc, Cc, 3, 1, 1, seed=16, scale=0.1)
+    b = torch.randn(Cc, generator=torch.Generator().manual_seed(17))
+    xt = x[..., 0].permute(0, 2, 3, 1).reshape(B * T * HW, Cc).contiguous()
+    out = ops.igemm(xt.to(DEV), pack_conv3d_t3(w).to(DEV), b.to(DEV), geom=ops.convt3_geom(T, HW))
+    ref = F.conv3d(x.float(), w.float(), b, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(-1, Cc)
+    _close(out, ref, what="conv3d (3,1,1)")
+
+
+def test_igemm_large_k_accumulation(ops):
+    M, N, K = 256, 256, 2560
+    x, w = _h(M, K, seed=18), _h(N, K, seed=19, scale=0.05)
+    out = ops.igemm(x.to(DEV), w.to(DEV))
+    _close(out, x.float() @ w.float().t(), what="igemm K=2560")
+
+
+def test_igemm_rejects_bad_args(ops):
+    from mofa_video_amd.lib import MofaHipError
+    x, w = _h(64, 48, seed=1).to(DEV), _h(64, 48, seed=2).to(DEV)  # Cin % 64 != 0
+    with pytest.raises(MofaHipError):
+        ops.igemm(x, w)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,heads,frames", [(200, 3, 2), (64, 1, 1), (16, 2, 3), (1024, 5, 2)])
+def test_attn_spatial(ops, S, heads, frames):
+    Cc = heads * 64
+    qkv = _h(frames * S, 3 * Cc, seed=20)
+    d = qkv.to(DEV)
+    out = ops.attn_spatial(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S)
+    q, k, v = [t.float().reshape(frames, S, heads, 64).transpose(1, 2) for t in qkv.split(Cc, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(frames * S, Cc)
+    _close(out, ref, tol=4e-3, what="attn spatial")
+
+
+def test_attn_spatial_online_softmax_rescale(ops):
+    """Force the running max to jump at a late key tile (rare-branch test)."""
+    S, heads, frames = 256, 1, 1
+    qkv = _h(S, 192, seed=21, scale=0.5)
+    qkv[200, 64:128] = qkv[5, 0:64] * 6.0  # key 200 strongly aligned with query 5
+    d = qkv.to(DEV)
+    out = ops.attn_spatial(d[:, :64], d[:, 64:128], d[:, 128:], frames, heads, S)
+    q, k, v = [t.float().reshape(1, S, 1, 64).transpose(1, 2) for t in qkv.split(64, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, 64)
+    _close(out, ref, tol=4e-3, what="attn spatial rescale")
+
+
+@pytest.mark.parametrize("T,HW,heads,clips", [(25, 37, 2, 2), (8, 16, 1, 2), (32, 5, 3, 1), (1, 9, 1, 1)])
+def test_attn_temporal(ops, T, HW, heads, clips):
+    Cc = heads * 64
+    qkv = _h(clips * T * HW, 3 * Cc, seed=22)
+    d = qkv.to(DEV)
+    out = ops.attn_temporal(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], clips, T, HW, heads)
+    q, k, v = [t.float().reshape(clips, T, HW, heads, 64).permute(0, 2, 3, 1, 4) for t in qkv.split(Cc, dim=1)]
+    ref = F.scaled_dot_product_attention(q, k, v)  # [clips, HW, heads, T, 64]
+    ref = ref.permute(0, 3, 1, 2, 4).reshape(clips * T * HW, Cc)
+    _close(out, ref, tol=2e-3, what="attn temporal")
+
+
+def test_softmax_rows_and_transpose(ops):
+    x = _h(33, 520, seed=23, scale=3.0)
+    out = ops.softmax_rows_(x.to(DEV).clone())
+    _close(out, torch.softmax(x.float(), dim=1), what="softmax rows")
+    frames, heads, S = 2, 3, 200
+    v = _h(frames * S, heads * 64 + 64, seed=24)
+    vt = ops.transpose_v(v.to(DEV)[:, 64:], frames, heads, S)
+    ref = v[:, 64:].reshape(frames, S, heads, 64).permute(0, 2, 3, 1).reshape(frames * heads * 64, S)
+    assert torch.equal(vt.cpu(), ref)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# normalisation
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,HW,frames,fps", [(320, 300, 4, 1), (64, 37, 6, 3), (2560, 20, 2, 1), (128, 5000, 2, 2)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm(ops, C, HW, frames, fps, silu):
+    x = _h(frames * HW, C, seed=25) + 0.5
+    g = torch.randn(C, generator=torch.Generator().manual_seed(26))
+    b = torch.randn(C, generator=torch.Generator().manual_seed(27))
+    out = ops.group_norm(x.to(DEV), g.to(DEV), b.to(DEV), frames, HW, 1e-5, frames_per_stat=fps, silu=silu)
+    xr = x.float().reshape(frames // fps, fps * HW, C).transpose(1, 2)  # [stat, C, L]
+    ref = F.group_norm(xr, 32, g, b, eps=1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.transpose(1, 2).reshape(frames * HW, C)
+    _close(out, ref, what="group norm")
+
+
+@pytest.mark.parametrize("C", [64, 320, 1280])
+def test_layer_norm(ops, C):
+    M = 101
+    x = _h(M, C, seed=28) * 2 + 0.3
+    g = torch.randn(C, generator=torch.Generator().manual_seed(29))
+    b = torch.randn(C, generator=torch.Generator().manual_seed(30))
+    rv = torch.randn(3, C, generator=torch.Generator().manual_seed(31))
+    out = ops.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, rowvec=rv.to(DEV), rv_div=10, rv_mod=3)
+    idx = (torch.arange(M) // 10) % 3
+    ref = F.layer_norm(x.float() + rv[idx], (C,), g, b, 1e-5)
+    _close(out, ref, what="layer norm + rowvec")
+    out2 = ops.layer_norm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5)
+    _close(out2, F.layer_norm(x.float(), (C,), g, b, 1e-5), what="layer norm")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# element-wise
+# ---------------------------------------------------------------------------------------------------------
+def test_elementwise(ops):
+    x, y = _h(50, 64, seed=32), _h(50, 64, seed=33)
+    out = ops.axpby_(x.to(DEV), y.to(DEV).clone(), 0.5, 2.0)
+    _close(out, 0.5 * x.float() + 2.0 * y.float(), tol=1e-3, what="axpby")
+    g = _h(50, 256, seed=34)
+    _close(ops.geglu(g.to(DEV)), g[:, :128].float() * F.gelu(g[:, 128:].float()), tol=1e-3, what="geglu")
+    a, b = _h(40, 64, seed=35), _h(40, 128, seed=36)
+    cat = ops.concat_channels(a.to(DEV), b.to(DEV))
+    assert torch.equal(cat.cpu(), torch.cat([a, b], 1))
+    v = torch.randn(300, generator=torch.Generator().manual_seed(37))
+    _close(ops.silu_f32(v.to(DEV)), F.silu(v), tol=1e-5, what="silu f32")
+    img = torch.randn(2, 3, 7, 9, generator=torch.Generator().manual_seed(38))
+    tok = ops.nchw_to_tokens(img.to(DEV), ld=64)
+    assert tok.shape == (2 * 63, 64) and tok[:, 3:].abs().max().item() == 0
+    _close(tok[:, :3], img.permute(0, 2, 3, 1).reshape(-1, 3), tol=1e-3, what="nchw->tokens")
+    back = ops.tokens_to_nchw(tok, 2, 3, 7, 9)
+    _close(back, img.half().float(), tol=1e-6, what="tokens->nchw")
+    assert torch.equal(ops.cast_f16_to_f32(ops.cast_f32_to_f16(v.to(DEV))).cpu(), v.half().float())
+
+
+def test_timestep_embedding_and_flow_downscale(ops):
+    from oracle.blocks import get_timestep_embedding
+    t = torch.tensor([1.6378, 6.0, 128.0, 0.02, 24.0])
+    out = ops.timestep_embedding(t.to(DEV), 320)
+    ref = get_timestep_embedding(t, 320, flip_sin_to_cos=True, downscale_freq_shift=0)
+    _close(out, ref, tol=2e-5, what="timestep embedding")
+    flow = torch.randn(3, 2, 64, 128, generator=torch.Generator().manual_seed(39)) * 20
+    for s in (8, 16, 32, 64):
+        ref = F.interpolate(flow, scale_factor=1 / s) / s
+        out = ops.flow_downscale(flow.to(DEV), s)
+        assert torch.equal(out.cpu(), ref)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# softsplat (vs the CPU oracle) and scheduler math
+# ---------------------------------------------------------------------------------------------------------
+def _flows(n, H, W, seed, mag):
+    g = torch.Generator().manual_seed(seed)
+    f = torch.randn(n, 2, H, W, generator=g) * mag
+    f[0, :, 0, 0] = float("nan")            # non-finite flow is skipped (softsplat.py:301-302)
+    f[-1, 0, 1, 1] = float("inf")
+    f[0, :, 2, 2] = torch.tensor([1.0, -2.0])  # integer shift
+    f[0, :, 3, 3] = torch.tensor([1000.0, 5.0])  # out of bounds
+    return f
+
+
+@pytest.mark.parametrize("H,W,C,mag", [(9, 16, 64, 1.5), (18, 32, 128, 4.0), (36, 64, 320, 0.3)])
+def test_softsplat_gather_vs_oracle(ops, H, W, C, mag):
+    from oracle.softsplat import softsplat
+    nfl = 5
+    feat = _h(1, C, H, W, seed=40)
+    flow = _flows(nfl, H, W, 41, mag)
+    tok = feat[0].permute(1, 2, 0).reshape(H * W, C).contiguous()
+    out = ops.softsplat_avg_tokens(tok.to(DEV), flow.to(DEV), H, W)
+    ref = torch.stack([softsplat(feat.float(), flow[i:i + 1], None, "avg")[0] for i in range(nfl)])
+    ref = ref.permute(0, 2, 3, 1).reshape(nfl * H * W, C)
+    _close(out, ref, tol=1.5e-3, what="softsplat gather")
+    # deterministic: bitwise reproducible run to run
+    out2 = ops.softsplat_avg_tokens(tok.to(DEV), flow.to(DEV), H, W)
+    assert torch.equal(out, out2)
+
+
+def test_softsplat_scatter_vs_oracle(ops):
+    from oracle.softsplat import softsplat_sum
+    N, C, H, W = 2, 7, 12, 20
+    x = torch.randn(N, C, H, W, generator=torch.Generator().manual_seed(42))
+    flow = _flows(N, H, W, 43, 2.0)
+    out = ops.softsplat_scatter_f32(x.to(DEV), flow.to(DEV))
+    _close(out, softsplat_sum(x, flow), tol=1e-5, what="softsplat scatter")
+
+
+def test_scheduler_kernels_vs_oracle(ops):
+    from oracle.scheduler import EulerDiscreteScheduler
+    T, h, w = 5, 6, 8
+    g = torch.Generator().manual_seed(44)
+    lat = torch.randn(T, 4, h, w, generator=g) * 50
+    img = torch.randn(2, 4, h, w, generator=g)
+    npred = (torch.randn(2, T, h * w, 4, generator=g)).half()
+    sch = EulerDiscreteScheduler()
+    sch.set_timesteps(25)
+    i = 3
+    sigma, sigma_next = sch.sigmas[i].item(), sch.sigmas[i + 1].item()
+    out = torch.zeros(2 * T * h * w, 64, dtype=torch.float16, device=DEV)
+    ops.prepare_model_input(lat.to(DEV), img.to(DEV), out, sigma)
+    ref_lat = (lat / (sigma ** 2 + 1) ** 0.5).permute(0, 2, 3, 1).reshape(T * h * w, 4)
+    ref_img = img.permute(0, 2, 3, 1).reshape(2, h * w, 4)
+    for half in range(2):
+        blk = out[half * T * h * w:(half + 1) * T * h * w]
+        _close(blk[:, :4], ref_lat, tol=1e-3, what="model input latents")
+        _close(blk[:, 4:8].reshape(T, h * w, 4), ref_img[half].expand(T, -1, -1), tol=1e-3, what="model input image")
+        assert blk[:, 8:].abs().max().item() == 0
+    # CFG + Euler vs the oracle scheduler
+    sch._step_index = i
+    npf = npred.float().reshape(2, T, h, w, 4).permute(0, 1, 4, 2, 3)  # [2,T,4,h,w]
+    gs = torch.linspace(1.0, 3.0, T).view(T, 1, 1, 1)
+    v = npf[0] + gs * (npf[1] - npf[0])
+    ref = sch.step(v, sch.timesteps[i], lat)
+    latd = lat.to(DEV).clone()
+    ops.cfg_euler_step_(latd, npred.to(DEV).reshape(2 * T * h * w, 4), sigma, sigma_next, 1.0, 3.0)
+    _close(latd, ref, tol=1e-5, what="cfg + euler")
