@@ -128,8 +128,9 @@ int mofa_silu_f32(const float* x, float* y, int n, mofa_stream_t stream);
 /* fp32 -> fp16 / fp16 -> fp32 contiguous casts */
 int mofa_cast_f32_to_f16(const float* x, void* y, int64_t n, mofa_stream_t stream);
 int mofa_cast_f16_to_f32(const void* x, float* y, int64_t n, mofa_stream_t stream);
-/* NCHW fp32 [n][C][H][W] -> token-major fp16 [n][H*W][ldo] (channels >= C left untouched) and back */
-int mofa_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int C, int HW, int ldo, mofa_stream_t stream);
+/* NCHW fp32 [n][C][H][W] * scale -> token-major fp16 [n][H*W][ldo] (channels >= C left untouched) and back */
+int mofa_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int C, int HW, int ldo, float scale,
+                              mofa_stream_t stream);
 int mofa_nhwc_f16_to_nchw_f32(const void* x, float* y, int n, int C, int HW, int ldx, mofa_stream_t stream);
 /* sinusoidal Timesteps(dim, flip_sin_to_cos=True, shift=0): out fp32 [n][dim]  (diffusers embeddings.py) */
 int mofa_timestep_embedding(const float* t, float* out, int n, int dim, mofa_stream_t stream);

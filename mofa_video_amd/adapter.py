@@ -1,0 +1,173 @@
+"""MI355X host mirror of the MOFA-Adapter (trajectory) ``FlowControlNet``.
+
+Reference: MOFA-Video-Traj/models/svdxt_featureflow_forward_controlnet_s2d_fixcmp_norefine.py
+  (FlowControlNetConditioningEmbeddingSVD :66-101, FlowControlNetFirstFrameEncoder :130-155,
+   FlowControlNet.get_warped_frames :223-234, FlowControlNet.forward :236-383)
+and MOFA-Video-Traj/models/controlnet_sdv.py:156-309 (trunk + 13 zero convs).
+
+``prepare_condition`` computes everything that depends only on (controlnet_cond, controlnet_flow): the
+condition embedding CNN, the first-frame pyramid, the 4 flow pyramids and all (T-1) x 4 forward-splat warps.
+The reference recomputes them every denoise step and for both CFG halves although they are timestep- and
+half-invariant; hoisting is results-identical.
+"""
+import torch
+
+from . import lib as L
+from . import ops
+from .blocks import BIG, Conv3x3, Ctx, DownBlock, Linear, MidBlock, Sub, TimeEmbedding
+from .unet import DEFAULT_CONFIG, _Config
+
+
+class _CondEmbedding:
+    """FlowControlNetConditioningEmbeddingSVD: 3->16->16->32->32->96->96->256->320, SiLU between."""
+
+    def __init__(self, s):
+        self.convs = [(Conv3x3(s.sub("conv_in")), True)]
+        i = 0
+        while s.has(f"blocks.{i}.weight"):
+            self.convs.append((Conv3x3(s.sub(f"blocks.{i}"), stride=2 if i % 2 == 1 else 1), True))
+            i += 1
+        self.convs.append((Conv3x3(s.sub("conv_out")), False))
+        self.in_ld = self.convs[0][0].w.shape[1] // 9
+
+    def __call__(self, x, H, W):
+        for conv, silu in self.convs:
+            n = conv.n_real
+            g = ops.conv3x3_geom(H, W, conv.stride, 1)
+            ld = (n + 63) // 64 * 64
+            out = torch.zeros((x.shape[0] // (H * W) * g.Hout * g.Wout, ld), dtype=torch.float16, device=x.device)
+            conv(x, H, W, act=L.ACT_SILU if silu else L.ACT_NONE, out=out)
+            x, H, W = out, g.Hout, g.Wout
+        return x, H, W
+
+
+class FlowControlNet:
+    def __init__(self, state_dict, config=None, device="cuda", dtype=torch.float16):
+        cfg = dict(DEFAULT_CONFIG)
+        cfg.update(config or {})
+        self.config = _Config(cfg)
+        self.device, self.dtype = torch.device(device), dtype
+        s = Sub(state_dict, "", device)
+        boc = tuple(cfg["block_out_channels"])
+        heads = tuple(cfg["num_attention_heads"])
+        n = len(boc)
+        lpb = cfg["layers_per_block"]
+        self.conv_in = Conv3x3(s.sub("conv_in"))
+        self.in_ld = self.conv_in.w.shape[1] // 9
+        self.time = TimeEmbedding(s, boc[0], cfg["addition_time_embed_dim"])
+        self.down_blocks = []
+        for i, t in enumerate(cfg["down_block_types"]):
+            self.down_blocks.append(DownBlock(s.sub(f"down_blocks.{i}"), lpb, heads[i], cross=t.startswith("CrossAttn"),
+                                              downsample=(i != n - 1)))
+        self.mid_block = MidBlock(s.sub("mid_block"), heads[-1])
+        nz = 0
+        while s.has(f"controlnet_down_blocks.{nz}.weight"):
+            nz += 1
+        self.controlnet_down_blocks = [Linear(s.sub(f"controlnet_down_blocks.{i}")) for i in range(nz)]
+        self.controlnet_mid_block = Linear(s.sub("controlnet_mid_block"))
+        self.cond_embedding = _CondEmbedding(s.sub("controlnet_cond_embedding"))
+        fe = s.sub("flow_encoder")
+        self.flow_encoders, self.flow_zeroconvs = [], []
+        i = 0
+        while fe.has(f"encoders.{i}.conv_in.weight"):
+            self.flow_encoders.append(Conv3x3(fe.sub(f"encoders.{i}.conv_in"), stride=2))
+            self.flow_zeroconvs.append(Linear(fe.sub(f"zeroconvs.{i}")) if fe.has(f"zeroconvs.{i}.weight") else None)
+            i += 1
+
+    @classmethod
+    def from_module(cls, module, device="cuda"):
+        return cls(module.state_dict(), getattr(module, "config", None), device)
+
+    # -- timestep-invariant adapter work (svdxt_...norefine.py:297-319) -------------------------------------
+    def prepare_condition(self, controlnet_cond, controlnet_flow):
+        """controlnet_cond [1,3,H,W]; controlnet_flow [1,T-1,2,H,W] -> list of 4 token-major fp16 tensors
+        [T*h_l*w_l, C_l]: frame 0 = the first-frame feature, frames 1.. = its forward-splat by flow 0->i."""
+        cond = controlnet_cond.to(self.device, torch.float32)
+        flow = controlnet_flow.to(self.device, torch.float32)
+        assert cond.shape[0] == 1 and flow.shape[0] == 1, "one clip per call (both CFG halves share it)"
+        _, _, H, W = cond.shape
+        x = ops.nchw_to_tokens(cond, ld=self.cond_embedding.in_ld)
+        f, h, w = self.cond_embedding(x, H, W)                              # [h*w, 320] at H/8
+        feats = [(f, h, w)]
+        e = f
+        for enc, zc in zip(self.flow_encoders, self.flow_zeroconvs):
+            e = enc(e, h, w, act=L.ACT_SILU)
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            feats.append((zc(e) if zc is not None else e, h, w))
+        fl = flow[0].contiguous()                                           # [T-1, 2, H, W]
+        warped = []
+        for (ft, h, w) in feats:
+            s = H // h
+            fs = ops.flow_downscale(fl, s)                                  # F.interpolate(nearest, 1/s) / s
+            wr = ops.softsplat_avg_tokens(ft, fs, h, w)                     # [(T-1)*h*w, C]
+            allf = torch.empty((ft.shape[0] + wr.shape[0], ft.shape[1]), dtype=torch.float16, device=self.device)
+            ops.copy2d(ft, allf[:ft.shape[0]])
+            ops.copy2d(wr, allf[ft.shape[0]:])
+            warped.append(allf)
+        return warped
+
+    def make_ctx(self, timestep, encoder_hidden_states, added_time_ids, B, T, base=None):
+        c = base if base is not None else Ctx(B, T)
+        ts = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
+        ts = ts.expand(B).contiguous() if ts.numel() == 1 else ts.contiguous()
+        c.temb_act = self.time(ts, added_time_ids.to(self.device, torch.float32).contiguous())
+        if c.ctx16 is None:
+            e = encoder_hidden_states.to(self.device, torch.float32).reshape(B, -1).contiguous()
+            c.ctx16 = ops.cast_f32_to_f16(e)
+        return c
+
+    def _add_warped(self, sample, warped, B):
+        rows = warped.shape[0]
+        for b in range(B):
+            ops.axpby_(warped, sample[b * rows:(b + 1) * rows], 1.0, 1.0)
+
+    def forward_tokens(self, x, c, H, W, warped, conditioning_scale=1.0):
+        """-> (12 residual token tensors, mid residual), already multiplied by conditioning_scale."""
+        B = c.B
+        cs = float(conditioning_scale)
+        sample = self.conv_in(x, H, W)
+        self._add_warped(sample, warped[0], B)                               # :328
+        zi = 0
+        outs = [self.controlnet_down_blocks[zi](sample, s_acc=cs)]           # zero conv applied eagerly so the
+        zi += 1                                                              # later in-place adds are safe
+        count, length = 1, len(warped)
+        for blk in self.down_blocks:
+            sample, H, W, res = blk(sample, c, H, W)
+            for (r, _, _) in res:
+                outs.append(self.controlnet_down_blocks[zi](r, s_acc=cs))
+                zi += 1
+            self._add_warped(sample, warped[min(count, length - 1)], B)      # :349
+            count += 1
+        self._add_warped(sample, warped[-1], B)                              # :354
+        sample = self.mid_block(sample, c, H, W)
+        mid = self.controlnet_mid_block(sample, s_acc=cs)
+        return outs, mid
+
+    # reference signature ------------------------------------------------------------------------------------
+    def forward(self, sample, timestep, encoder_hidden_states, added_time_ids, controlnet_cond=None,
+                controlnet_flow=None, image_only_indicator=None, return_dict=True, guess_mode=False,
+                conditioning_scale=1.0):
+        B, T, Cin, H, W = sample.shape
+        c = self.make_ctx(timestep, encoder_hidden_states, added_time_ids, B, T)
+        # the reference feeds identical cond/flow to both CFG halves (pipeline.py:393-397); the warp set is
+        # computed from batch element 0 and shared
+        warped = self.prepare_condition(controlnet_cond[:1], controlnet_flow[:1])
+        x = ops.nchw_to_tokens(sample.reshape(B * T, Cin, H, W).to(self.device, torch.float32), ld=self.in_ld)
+        outs, mid = self.forward_tokens(x, c, H, W, warped, conditioning_scale)
+        dims = []
+        h, w = H, W
+        dims.append((h, w))
+        for i, blk in enumerate(self.down_blocks):
+            for _ in blk.resnets:
+                dims.append((h, w))
+            if blk.down is not None:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                dims.append((h, w))
+        res = [ops.tokens_to_nchw(o, B * T, o.shape[1], hh, ww).to(sample.dtype) for o, (hh, ww) in zip(outs, dims)]
+        midn = ops.tokens_to_nchw(mid, B * T, mid.shape[1], h, w).to(sample.dtype)
+        if not return_dict:
+            return (res, midn, controlnet_flow, None)
+        return _Config(down_block_res_samples=res, mid_block_res_sample=midn, controlnet_flow=controlnet_flow,
+                       cmp_output=None)
+
+    __call__ = forward

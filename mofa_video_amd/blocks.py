@@ -1,0 +1,318 @@
+"""Host-side block graph of the SVD spatio-temporal UNet / ControlNet trunk / temporal VAE decoder.
+
+These classes only *sequence* launches of libmofa_hip.so (``ops``) over token-major fp16 activations;
+they hold repacked weights and no torch arithmetic.  Parameter names are the diffusers==0.24.0 names
+the reference checkpoints use, so ``from_state_dict`` consumes an unmodified checkpoint
+``state_dict``.
+
+Fusions relative to the reference module graph (all results-identical in exact arithmetic):
+  * conv/linear bias, "+ time-embedding" broadcast, residual adds, AlphaBlender and the ControlNet
+    ``conditioning_scale`` are igemm epilogues;
+  * cross-attention to the single image-embedding token: softmax over one key == 1, so
+    attn2(x) = to_out(to_v(ctx)) is a per-clip row vector added in the attn1.to_out epilogue
+    (to_q / to_k / norm2 are mathematically dead);
+  * GEGLU is formed in the projection GEMM's epilogue (value/gate weight rows interleaved at load);
+  * the frame-position embedding add is folded into norm_in and the ff_in output epilogue.
+"""
+import math
+
+import torch
+
+from . import lib as L
+from . import ops
+from .weights import (f32, interleave_geglu, pack_conv3d_t3, pack_conv3x3, pack_linear, pad_rows)
+
+BIG = 1 << 30
+
+
+class Sub:
+    """prefix view of a flat state_dict"""
+
+    def __init__(self, sd, prefix="", device="cuda"):
+        self.sd, self.prefix, self.device = sd, prefix, device
+
+    def sub(self, name):
+        return Sub(self.sd, f"{self.prefix}{name}.", self.device)
+
+    def has(self, name):
+        return f"{self.prefix}{name}" in self.sd
+
+    def get(self, name):
+        return self.sd[f"{self.prefix}{name}"].detach()
+
+    def dev(self, t):
+        return t.to(self.device)
+
+
+class Ctx:
+    """Per-forward geometry + conditioning vectors shared by all blocks."""
+
+    def __init__(self, B, T):
+        self.B, self.T = B, T
+        self.N = B * T
+        self.temb_act = None      # fp16 [B, temb_dim] = silu(emb); None for the VAE
+        self.ctx16 = None         # fp16 [B, cross_dim] image embedding (first frame's == every frame's)
+        self.cache = {}           # timestep-invariant per-layer vectors (cross-attention, frame-position emb)
+        self.time_context_hw_major = True
+
+
+# ---------------------------------------------------------------------------------------------------------
+class Linear:
+    def __init__(self, s, pad_n=False):
+        w = s.get("weight")
+        w = w.reshape(w.shape[0], -1)
+        self.n_real = w.shape[0]
+        b = s.get("bias") if s.has("bias") else None
+        if pad_n:
+            w = pad_rows(w)
+            b = pad_rows(b) if b is not None else None
+        self.w = s.dev(pack_linear(w))
+        self.b = s.dev(f32(b)) if b is not None else None
+
+    def __call__(self, x, **kw):
+        return ops.igemm(x, self.w, self.b, **kw)
+
+
+class Conv3x3:
+    def __init__(self, s, stride=1, up=1, pad_n=False):
+        w, b = s.get("weight"), s.get("bias")
+        self.n_real = w.shape[0]
+        if pad_n:
+            w, b = pad_rows(w), pad_rows(b)
+        self.w = s.dev(pack_conv3x3(w))
+        self.b = s.dev(f32(b))
+        self.stride, self.up = stride, up
+
+    def __call__(self, x, H, W, **kw):
+        return ops.igemm(x, self.w, self.b, geom=ops.conv3x3_geom(H, W, self.stride, self.up), **kw)
+
+
+class ConvT3:
+    def __init__(self, s, pad_n=False):
+        w, b = s.get("weight"), s.get("bias")
+        if pad_n:
+            w, b = pad_rows(w), pad_rows(b)
+        self.w = s.dev(pack_conv3d_t3(w))
+        self.b = s.dev(f32(b))
+
+    def __call__(self, x, T, HW, **kw):
+        return ops.igemm(x, self.w, self.b, geom=ops.convt3_geom(T, HW), **kw)
+
+
+class GroupNorm:
+    def __init__(self, s, eps):
+        self.g, self.b, self.eps = s.dev(f32(s.get("weight"))), s.dev(f32(s.get("bias"))), eps
+
+    def __call__(self, x, nframes, HW, frames_per_stat=1, silu=False):
+        return ops.group_norm(x, self.g, self.b, nframes, HW, self.eps, frames_per_stat, silu)
+
+
+class LayerNorm:
+    def __init__(self, s, eps=1e-5):
+        self.g, self.b, self.eps = s.dev(f32(s.get("weight"))), s.dev(f32(s.get("bias"))), eps
+
+    def __call__(self, x, **kw):
+        return ops.layer_norm(x, self.g, self.b, self.eps, **kw)
+
+
+class GegluFF:
+    """diffusers FeedForward(dim, activation_fn='geglu'): net.0.proj (-> 8C), net.2 (4C -> dim_out)."""
+
+    def __init__(self, s):
+        w, b = interleave_geglu(s.get("net.0.proj.weight"), s.get("net.0.proj.bias"))
+        self.w1, self.b1 = s.dev(pack_linear(w)), s.dev(f32(b))
+        self.out = Linear(s.sub("net.2"))
+
+    def __call__(self, x, **epilogue):
+        h = ops.igemm(x, self.w1, self.b1, act=L.ACT_GEGLU_PAIR)
+        return self.out(h, **epilogue)
+
+
+def _sigmoid(v):
+    return 1.0 / (1.0 + math.exp(-float(v)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+class SpatioTemporalResBlock:
+    """diffusers SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender."""
+
+    def __init__(self, s, eps, temporal_eps=None, switch=False):
+        sp, tp = s.sub("spatial_res_block"), s.sub("temporal_res_block")
+        self.norm1, self.norm2 = GroupNorm(sp.sub("norm1"), eps), GroupNorm(sp.sub("norm2"), eps)
+        self.conv1, self.conv2 = Conv3x3(sp.sub("conv1")), Conv3x3(sp.sub("conv2"))
+        self.temb = Linear(sp.sub("time_emb_proj")) if sp.has("time_emb_proj.weight") else None
+        self.shortcut = Linear(sp.sub("conv_shortcut")) if sp.has("conv_shortcut.weight") else None
+        te = temporal_eps if temporal_eps is not None else eps
+        self.tnorm1, self.tnorm2 = GroupNorm(tp.sub("norm1"), te), GroupNorm(tp.sub("norm2"), te)
+        self.tconv1, self.tconv2 = ConvT3(tp.sub("conv1")), ConvT3(tp.sub("conv2"))
+        self.ttemb = Linear(tp.sub("time_emb_proj")) if tp.has("time_emb_proj.weight") else None
+        alpha = _sigmoid(s.get("time_mixer.mix_factor").reshape(-1)[0])
+        self.alpha = (1.0 - alpha) if switch else alpha   # weight of x_spatial
+
+    def __call__(self, x, c, H, W):
+        HW, N, T = H * W, c.N, c.T
+        rv = dict(rv=(T * HW, 1, 1, BIG))
+        h = self.norm1(x, N, HW, silu=True)
+        if self.temb is not None:
+            tv = ops.cast_f16_to_f32(self.temb(c.temb_act))
+            h = self.conv1(h, H, W, rowvec=tv, **rv)
+        else:
+            h = self.conv1(h, H, W)
+        h = self.norm2(h, N, HW, silu=True)
+        xs = self.shortcut(x) if self.shortcut is not None else x
+        xs = self.conv2(h, H, W, r1=xs, s1=1.0)                          # ResnetBlock2D output
+        g = self.tnorm1(xs, N, HW, frames_per_stat=T, silu=True)
+        if self.ttemb is not None:
+            tv = ops.cast_f16_to_f32(self.ttemb(c.temb_act))
+            g = self.tconv1(g, T, HW, rowvec=tv, **rv)
+        else:
+            g = self.tconv1(g, T, HW)
+        g = self.tnorm2(g, N, HW, frames_per_stat=T, silu=True)
+        # alpha*xs + (1-alpha)*(xs + conv) = xs + (1-alpha)*conv
+        return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0)
+
+
+class CrossAttnVec:
+    """attn2 with a single key token: output row vector to_out(to_v(ctx)) + bias per clip."""
+
+    def __init__(self, s):
+        self.to_v = Linear(s.sub("to_v"))
+        self.to_out = Linear(s.sub("to_out.0"))
+
+    def __call__(self, ctx16):
+        return ops.cast_f16_to_f32(self.to_out(self.to_v(ctx16)))       # fp32 [B, C]
+
+
+class SelfAttn:
+    def __init__(self, s, heads):
+        w = torch.cat([s.get("to_q.weight"), s.get("to_k.weight"), s.get("to_v.weight")], 0)
+        self.wqkv = s.dev(pack_linear(w))
+        self.to_out = Linear(s.sub("to_out.0"))
+        self.heads = heads
+        self.C = heads * 64
+
+    def qkv(self, x):
+        qkv = ops.igemm(x, self.wqkv)
+        Cc = self.C
+        return qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+
+
+class TransformerSpatioTemporal:
+    """diffusers TransformerSpatioTemporalModel (one spatial + one temporal transformer block)."""
+    _uid = 0
+
+    def __init__(self, s, heads):
+        TransformerSpatioTemporal._uid += 1
+        self.uid = TransformerSpatioTemporal._uid
+        self.heads = heads
+        self.norm = GroupNorm(s.sub("norm"), 1e-6)
+        self.proj_in, self.proj_out = Linear(s.sub("proj_in")), Linear(s.sub("proj_out"))
+        b = s.sub("transformer_blocks.0")
+        self.norm1, self.norm3 = LayerNorm(b.sub("norm1")), LayerNorm(b.sub("norm3"))
+        self.attn1, self.attn2, self.ff = SelfAttn(b.sub("attn1"), heads), CrossAttnVec(b.sub("attn2")), GegluFF(b.sub("ff"))
+        t = s.sub("temporal_transformer_blocks.0")
+        self.norm_in, self.tnorm1, self.tnorm3 = LayerNorm(t.sub("norm_in")), LayerNorm(t.sub("norm1")), LayerNorm(t.sub("norm3"))
+        self.ff_in, self.tattn1, self.tattn2, self.tff = (GegluFF(t.sub("ff_in")), SelfAttn(t.sub("attn1"), heads),
+                                                          CrossAttnVec(t.sub("attn2")), GegluFF(t.sub("ff")))
+        self.pos1, self.pos2 = Linear(s.sub("time_pos_embed.linear_1")), Linear(s.sub("time_pos_embed.linear_2"))
+        self.alpha = _sigmoid(s.get("time_mixer.mix_factor").reshape(-1)[0])
+        self.C = self.proj_in.w.shape[1]
+
+    def _invariants(self, c):
+        key = ("xf", self.uid)
+        if key not in c.cache:
+            dev = self.proj_in.w.device
+            tpos = ops.timestep_embedding(torch.arange(c.T, dtype=torch.float32, device=dev), self.C)
+            e = self.pos2(self.pos1(ops.cast_f32_to_f16(tpos), act=L.ACT_SILU))
+            c.cache[key] = (self.attn2(c.ctx16), self.tattn2(c.ctx16), ops.cast_f16_to_f32(e))
+        return c.cache[key]
+
+    def __call__(self, x, c, H, W):
+        HW, N, T, B = H * W, c.N, c.T, c.B
+        v_sp, v_tm, pos = self._invariants(c)
+        h = self.norm(x, N, HW)
+        h = self.proj_in(h)
+        # --- spatial BasicTransformerBlock ---
+        q, k, v = self.attn1.qkv(self.norm1(h))
+        a = ops.attn_spatial(q, k, v, N, self.heads, HW)
+        h = self.attn1.to_out(a, r1=h, s1=1.0, rowvec=v_sp, rv=(T * HW, 1, 1, BIG))      # + attn1 + attn2
+        h = self.ff(self.norm3(h), r1=h, s1=1.0)                                          # x_spatial
+        # --- TemporalBasicTransformerBlock on h + pos[t] ---
+        pos_rv = (HW, 1, 1, T)
+        f = self.ff_in(self.norm_in(h, rowvec=pos, rv_div=HW, rv_mod=T), r1=h, s1=1.0, rowvec=pos, rv=pos_rv)
+        q, k, v = self.tattn1.qkv(self.tnorm1(f))
+        a = ops.attn_temporal(q, k, v, B, T, HW, self.heads)
+        quirk = (T * HW, HW, HW, B) if c.time_context_hw_major else (T * HW, 1, 1, BIG)
+        f = self.tattn1.to_out(a, r1=f, s1=1.0, rowvec=v_tm, rv=quirk)
+        al = self.alpha
+        m = self.tff(self.tnorm3(f), s_acc=1.0 - al, r1=f, s1=1.0 - al, r2=h, s2=al)      # AlphaBlender
+        return self.proj_out(m, r1=x, s1=1.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+class DownBlock:
+    def __init__(self, s, num_layers, heads, cross, downsample):
+        eps = 1e-6 if cross else 1e-5
+        self.resnets = [SpatioTemporalResBlock(s.sub(f"resnets.{i}"), eps) for i in range(num_layers)]
+        self.attns = [TransformerSpatioTemporal(s.sub(f"attentions.{i}"), heads) for i in range(num_layers)] if cross else None
+        self.down = Conv3x3(s.sub("downsamplers.0.conv"), stride=2) if downsample else None
+
+    def __call__(self, x, c, H, W):
+        outs = []
+        for i, r in enumerate(self.resnets):
+            x = r(x, c, H, W)
+            if self.attns is not None:
+                x = self.attns[i](x, c, H, W)
+            outs.append((x, H, W))
+        if self.down is not None:
+            x = self.down(x, H, W)
+            H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            outs.append((x, H, W))
+        return x, H, W, outs
+
+
+class MidBlock:
+    def __init__(self, s, heads):
+        self.res0 = SpatioTemporalResBlock(s.sub("resnets.0"), 1e-5)
+        self.attn = TransformerSpatioTemporal(s.sub("attentions.0"), heads)
+        self.res1 = SpatioTemporalResBlock(s.sub("resnets.1"), 1e-5)
+
+    def __call__(self, x, c, H, W):
+        return self.res1(self.attn(self.res0(x, c, H, W), c, H, W), c, H, W)
+
+
+class UpBlock:
+    def __init__(self, s, num_layers, heads, cross, upsample):
+        self.resnets = [SpatioTemporalResBlock(s.sub(f"resnets.{i}"), 1e-6) for i in range(num_layers)]
+        self.attns = [TransformerSpatioTemporal(s.sub(f"attentions.{i}"), heads) for i in range(num_layers)] if cross else None
+        self.up = Conv3x3(s.sub("upsamplers.0.conv"), up=2) if upsample else None
+
+    def __call__(self, x, skips, c, H, W):
+        for i, r in enumerate(self.resnets):
+            x = ops.concat_channels(x, skips.pop())
+            x = r(x, c, H, W)
+            if self.attns is not None:
+                x = self.attns[i](x, c, H, W)
+        if self.up is not None:
+            x = self.up(x, H, W)
+            H, W = H * 2, W * 2
+        return x, H, W
+
+
+class TimeEmbedding:
+    """time_proj/time_embedding + add_time_proj/add_embedding (unet_..._controlnet.py:386-417)."""
+
+    def __init__(self, s, c0, add_dim):
+        self.c0, self.add_dim = c0, add_dim
+        self.l1, self.l2 = Linear(s.sub("time_embedding.linear_1")), Linear(s.sub("time_embedding.linear_2"))
+        self.a1, self.a2 = Linear(s.sub("add_embedding.linear_1")), Linear(s.sub("add_embedding.linear_2"))
+
+    def __call__(self, timesteps, added_time_ids):
+        """timesteps fp32 [B]; added_time_ids fp32 [B,3] -> fp16 silu(emb) [B, 4*c0]"""
+        B = timesteps.numel()
+        t = ops.cast_f32_to_f16(ops.timestep_embedding(timesteps, self.c0))
+        e = self.l2(self.l1(t, act=L.ACT_SILU))
+        a = ops.timestep_embedding(added_time_ids.reshape(-1).contiguous(), self.add_dim).reshape(B, -1)
+        a = ops.cast_f32_to_f16(a)
+        e = self.a2(self.a1(a, act=L.ACT_SILU), r1=e, s1=1.0)
+        return ops.cast_f32_to_f16(ops.silu_f32(ops.cast_f16_to_f32(e)))

@@ -103,7 +103,7 @@ extern "C" int mofa_cast_f16_to_f32(const void* x, float* y, int64_t n, mofa_str
 
 // NCHW fp32 -> token-major fp16 (through an LDS tile so both sides are coalesced)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, f16* __restrict__ y, int C, int HW,
-                                                           int ldo) {
+                                                           int ldo, float scale) {
     __shared__ float tile[32][33];
     const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32, n = blockIdx.z;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
@@ -114,13 +114,14 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
         const int p = p0 + r, c = c0 + tx;
-        if (p < HW && c < C) y[((size_t)n * HW + p) * ldo + c] = (f16)tile[tx][r];
+        if (p < HW && c < C) y[((size_t)n * HW + p) * ldo + c] = (f16)(tile[tx][r] * scale);
     }
 }
-extern "C" int mofa_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int C, int HW, int ldo, mofa_stream_t stream) {
+extern "C" int mofa_nchw_f32_to_nhwc_f16(const float* x, void* y, int n, int C, int HW, int ldo, float scale,
+                                         mofa_stream_t stream) {
     if (!x || !y || n <= 0 || C <= 0 || HW <= 0 || ldo < C) return MOFA_EINVAL;
     dim3 grid(cdiv(HW, 32), cdiv(C, 32), n);
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (f16*)y, C, HW, ldo);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (f16*)y, C, HW, ldo, scale);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

@@ -54,7 +54,7 @@ PROTOTYPES = {
     "mofa_silu_f32": [_P, _P, _I, _P],
     "mofa_cast_f32_to_f16": [_P, _P, _L, _P],
     "mofa_cast_f16_to_f32": [_P, _P, _L, _P],
-    "mofa_nchw_f32_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_nchw_f32_to_nhwc_f16": [_P, _P, _I, _I, _I, _I, _F, _P],
     "mofa_nhwc_f16_to_nchw_f32": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_timestep_embedding": [_P, _P, _I, _I, _P],
     "mofa_softsplat_ws_bytes": [_I, _I, _I],

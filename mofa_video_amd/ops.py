@@ -227,14 +227,14 @@ def cast_f16_to_f32(x):
     return y
 
 
-def nchw_to_tokens(x, ld=None):
+def nchw_to_tokens(x, ld=None, scale=1.0):
     """fp32 [n,C,H,W] -> fp16 token-major [n*H*W, ld] (zero-padded channels when ld > C)."""
     lib = L.load()
     _chk(x, F32)
     n, Cc, H, W = x.shape
     ld = ld or Cc
     y = (torch.zeros if ld > Cc else torch.empty)((n * H * W, ld), dtype=F16, device=x.device)
-    L.check(lib.mofa_nchw_f32_to_nhwc_f16(L.ptr(x.contiguous()), L.ptr(y), n, Cc, H * W, ld, L.stream_ptr()),
+    L.check(lib.mofa_nchw_f32_to_nhwc_f16(L.ptr(x.contiguous()), L.ptr(y), n, Cc, H * W, ld, float(scale), L.stream_ptr()),
             "mofa_nchw_f32_to_nhwc_f16")
     return y
 

@@ -1,0 +1,148 @@
+"""MI355X host mirror of ``FlowControlNetPipeline`` (MOFA-Video-Traj/pipeline/pipeline.py:87-527).
+
+Same constructor modules and ``__call__`` signature / defaults / return type.  The denoise loop runs
+entirely in libmofa_hip.so on token-major fp16 activations:
+
+    per clip (hoisted, timestep-invariant -- SURVEY F7/F11):
+        adapter.prepare_condition  (cond CNN, first-frame pyramid, flow pyramids, 96 forward-splat warps)
+        cross-attention row vectors and frame-position embeddings of every transformer layer
+    per step:
+        mofa_prepare_model_input   (scale by 1/sqrt(sigma^2+1), concat image latents, both CFG halves)
+        FlowControlNet.forward_tokens -> 12 + 1 residuals
+        UNet.forward_tokens           -> noise prediction
+        mofa_cfg_euler_step         (CFG with per-frame guidance + v-prediction Euler step, fp32 latents)
+    decode: temporal VAE decoder, chunks of ``decode_chunk_size`` frames.
+
+The CLIP image encoder and the VAE *encoder* run once per clip before the hot path and are not part of this
+package: pass ``image_embeddings`` ([1,1,1024] or [2,1,1024]) and ``image_latents``
+([1,4,h,w] or [2,4,h,w]) directly, or supply ``image_encoder`` / a ``vae`` with ``encode`` yourself.
+Reference quirks kept: ``added_time_ids`` is always [6, 128, 0.02] (pipeline.py:430-440); CFG is always on
+(max_guidance_scale > 1); the scheduler's unused per-step randn draw is not reproduced (no effect on results).
+"""
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .blocks import Ctx
+from .vae import decode_latents
+
+
+@dataclass
+class FlowControlNetPipelineOutput:
+    frames: Union[List, np.ndarray, torch.FloatTensor]
+    controlnet_flow: Union[List, np.ndarray, torch.FloatTensor]
+
+
+def _to_tensor_image(image, height, width, device):
+    """VaeImageProcessor.preprocess for tensors in [0,1] / [-1,1] is a resize + (2x-1); here only tensors that
+    are already H x W are accepted (resizing belongs to the once-per-clip front end)."""
+    if not torch.is_tensor(image):
+        raise ValueError("mofa_video_amd pipeline expects a torch tensor [1,3,H,W] in [-1,1] for image / "
+                         f"controlnet_condition (PIL preprocessing is outside the hot path), got {type(image)}")
+    if image.dim() == 3:
+        image = image.unsqueeze(0)
+    if tuple(image.shape[-2:]) != (height, width):
+        raise ValueError(f"image is {tuple(image.shape[-2:])}, expected ({height}, {width})")
+    return image.to(device, torch.float32)
+
+
+class FlowControlNetPipeline:
+    def __init__(self, vae=None, image_encoder=None, unet=None, controlnet=None, scheduler=None,
+                 feature_extractor=None):
+        self.vae, self.image_encoder, self.unet, self.controlnet = vae, image_encoder, unet, controlnet
+        self.scheduler, self.feature_extractor = scheduler, feature_extractor
+        self.vae_scale_factor = 8
+        self.device = unet.device
+
+    def check_inputs(self, image, height, width):                      # pipeline.py:222-234
+        if image is not None and not torch.is_tensor(image) and not isinstance(image, list):
+            raise ValueError("`image` has to be of type `torch.FloatTensor` or `PIL.Image.Image` or "
+                             f"`List[PIL.Image.Image]` but is {type(image)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+
+    def prepare_latents(self, batch_size, num_frames, num_channels_latents, height, width, generator, latents=None):
+        shape = (batch_size, num_frames, num_channels_latents // 2, height // 8, width // 8)
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, dtype=torch.float32,
+                                  device=generator.device if generator is not None else "cpu")
+        return latents.to(self.device, torch.float32) * self.scheduler.init_noise_sigma   # :272
+
+    # ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def __call__(self, image=None, controlnet_condition=None, controlnet_flow=None, height: int = 576,
+                 width: int = 1024, num_frames: Optional[int] = None, num_inference_steps: int = 25,
+                 min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0, fps: int = 7,
+                 motion_bucket_id: int = 127, noise_aug_strength: float = 0.02,
+                 decode_chunk_size: Optional[int] = None, num_videos_per_prompt: Optional[int] = 1,
+                 generator=None, latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pt",
+                 callback_on_step_end: Optional[Callable[[int, int, Dict], None]] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], return_dict: bool = True,
+                 controlnet_cond_scale=1.0, batch_size=1, *, image_embeddings=None, image_latents=None):
+        unet, cn, sch, dev = self.unet, self.controlnet, self.scheduler, self.device
+        num_frames = num_frames if num_frames is not None else unet.config.num_frames
+        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
+        self.check_inputs(image, height, width)
+        if batch_size != 1 or num_videos_per_prompt != 1:
+            raise ValueError("one clip per call (as every reference entry point does)")
+        if not max_guidance_scale > 1.0:
+            raise ValueError("the reference pipeline is only well-defined with classifier-free guidance on")
+        h, w = height // 8, width // 8
+        T = num_frames
+
+        # 3./4. image conditioning (computed before the hot path)
+        if image_embeddings is None:
+            if self.image_encoder is None:
+                raise ValueError("pass image_embeddings=... (CLIP runs outside the hot path)")
+            image_embeddings = self.image_encoder(image)
+        if image_latents is None:
+            if self.vae is None or not hasattr(self.vae, "encode"):
+                raise ValueError("pass image_latents=... (VAE encode runs outside the hot path)")
+            image_latents = self.vae.encode(image)
+        emb = image_embeddings.to(dev, torch.float32).reshape(-1, 1, image_embeddings.shape[-1])
+        if emb.shape[0] == 1:                                             # :133-139 uncond = zeros
+            emb = torch.cat([torch.zeros_like(emb), emb])
+        il = image_latents.to(dev, torch.float32)
+        if il.shape[0] == 1:                                              # :153-159
+            il = torch.cat([torch.zeros_like(il), il])
+        il = il.contiguous()
+
+        # 4./5. schedule + latents
+        sch.set_timesteps(num_inference_steps)
+        timesteps = sch.timesteps
+        lat = self.prepare_latents(1, T, unet.config.in_channels, height, width, generator, latents)
+        lat = lat.reshape(T, 4, h, w).contiguous()
+
+        # adapter condition: identical for both CFG halves (:393-397) -> computed once
+        cond = _to_tensor_image(controlnet_condition, height, width, dev)
+        flow = controlnet_flow.to(dev, torch.float32)
+        warped = cn.prepare_condition(cond[:1], flow[:1])
+        added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)   # :430-440
+
+        c_cn, c_un = Ctx(2, T), Ctx(2, T)                                 # hold the per-clip invariant caches
+        x_in = torch.zeros((2 * T * h * w, max(unet.in_ld, cn.in_ld)), dtype=torch.float16, device=dev)
+        self._num_timesteps = len(timesteps)
+        for i, t in enumerate(timesteps):                                 # :447-511
+            sigma, sigma_next = sch.sigma_pair(i)
+            ops.prepare_model_input(lat, il, x_in, sigma)
+            cn.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_cn)
+            down_res, mid_res = cn.forward_tokens(x_in, c_cn, h, w, warped, controlnet_cond_scale)
+            unet.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_un)
+            noise = unet.forward_tokens(x_in, c_un, h, w, down_res, mid_res)
+            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
+            if callback_on_step_end is not None:
+                out = callback_on_step_end(self, i, t, {"latents": lat.reshape(1, T, 4, h, w)})
+                if out and "latents" in out:
+                    lat = out["latents"].to(dev, torch.float32).reshape(T, 4, h, w).contiguous()
+
+        latents_out = lat.reshape(1, T, 4, h, w)
+        if output_type == "latent":
+            frames = latents_out
+        else:
+            frames = decode_latents(self.vae, latents_out, T, decode_chunk_size)       # fp32 [1,3,T,H,W]
+        if not return_dict:
+            return frames, controlnet_flow
+        return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)

@@ -1,0 +1,198 @@
+"""Checkpoint schema of the hot-path models: ``{state_dict key: shape}`` in the diffusers==0.24.0 layout the
+reference checkpoints use (SURVEY.md 8b "state_dict keys that must load unchanged"), plus a seeded
+synthetic-weight generator (no checkpoints exist offline).  Host-side only.
+"""
+import math
+
+import torch
+
+from .unet import DEFAULT_CONFIG
+
+
+def _lin(d, p, n, k, bias=True):
+    d[p + ".weight"] = (n, k)
+    if bias:
+        d[p + ".bias"] = (n,)
+
+
+def _norm(d, p, c):
+    d[p + ".weight"] = (c,)
+    d[p + ".bias"] = (c,)
+
+
+def _conv(d, p, n, c, *k):
+    d[p + ".weight"] = (n, c) + tuple(k)
+    d[p + ".bias"] = (n,)
+
+
+def _resblock(d, p, cin, cout, temb):
+    sp, tp = p + ".spatial_res_block", p + ".temporal_res_block"
+    _norm(d, sp + ".norm1", cin)
+    _conv(d, sp + ".conv1", cout, cin, 3, 3)
+    if temb:
+        _lin(d, sp + ".time_emb_proj", cout, temb)
+    _norm(d, sp + ".norm2", cout)
+    _conv(d, sp + ".conv2", cout, cout, 3, 3)
+    if cin != cout:
+        _conv(d, sp + ".conv_shortcut", cout, cin, 1, 1)
+    _norm(d, tp + ".norm1", cout)
+    _conv(d, tp + ".conv1", cout, cout, 3, 1, 1)
+    if temb:
+        _lin(d, tp + ".time_emb_proj", cout, temb)
+    _norm(d, tp + ".norm2", cout)
+    _conv(d, tp + ".conv2", cout, cout, 3, 1, 1)
+    d[p + ".time_mixer.mix_factor"] = (1,)
+
+
+def _attn(d, p, c, kv, bias=False):
+    _lin(d, p + ".to_q", c, c, bias)
+    _lin(d, p + ".to_k", c, kv, bias)
+    _lin(d, p + ".to_v", c, kv, bias)
+    _lin(d, p + ".to_out.0", c, c, True)
+
+
+def _ff(d, p, c):
+    _lin(d, p + ".net.0.proj", 8 * c, c)
+    _lin(d, p + ".net.2", c, 4 * c)
+
+
+def _transformer(d, p, c, cross):
+    _norm(d, p + ".norm", c)
+    _lin(d, p + ".proj_in", c, c)
+    b = p + ".transformer_blocks.0"
+    _norm(d, b + ".norm1", c); _attn(d, b + ".attn1", c, c)
+    _norm(d, b + ".norm2", c); _attn(d, b + ".attn2", c, cross)
+    _norm(d, b + ".norm3", c); _ff(d, b + ".ff", c)
+    t = p + ".temporal_transformer_blocks.0"
+    _norm(d, t + ".norm_in", c); _ff(d, t + ".ff_in", c)
+    _norm(d, t + ".norm1", c); _attn(d, t + ".attn1", c, c)
+    _norm(d, t + ".norm2", c); _attn(d, t + ".attn2", c, cross)
+    _norm(d, t + ".norm3", c); _ff(d, t + ".ff", c)
+    _lin(d, p + ".time_pos_embed.linear_1", 4 * c, c)
+    _lin(d, p + ".time_pos_embed.linear_2", c, 4 * c)
+    d[p + ".time_mixer.mix_factor"] = (1,)
+    _lin(d, p + ".proj_out", c, c)
+
+
+def _trunk(d, cfg):
+    """conv_in, embeddings, down blocks, mid block -- shared by UNet and ControlNet."""
+    boc = tuple(cfg["block_out_channels"])
+    temb = boc[0] * 4
+    cross = cfg["cross_attention_dim"]
+    lpb = cfg["layers_per_block"]
+    _conv(d, "conv_in", boc[0], cfg["in_channels"], 3, 3)
+    _lin(d, "time_embedding.linear_1", temb, boc[0]); _lin(d, "time_embedding.linear_2", temb, temb)
+    _lin(d, "add_embedding.linear_1", temb, cfg["projection_class_embeddings_input_dim"])
+    _lin(d, "add_embedding.linear_2", temb, temb)
+    out = boc[0]
+    for i, t in enumerate(cfg["down_block_types"]):
+        cin, out = out, boc[i]
+        for j in range(lpb):
+            _resblock(d, f"down_blocks.{i}.resnets.{j}", cin if j == 0 else out, out, temb)
+            if t.startswith("CrossAttn"):
+                _transformer(d, f"down_blocks.{i}.attentions.{j}", out, cross)
+        if i != len(boc) - 1:
+            _conv(d, f"down_blocks.{i}.downsamplers.0.conv", out, out, 3, 3)
+    _resblock(d, "mid_block.resnets.0", boc[-1], boc[-1], temb)
+    _transformer(d, "mid_block.attentions.0", boc[-1], cross)
+    _resblock(d, "mid_block.resnets.1", boc[-1], boc[-1], temb)
+    return temb, cross
+
+
+def unet_schema(config=None):
+    cfg = dict(DEFAULT_CONFIG); cfg.update(config or {})
+    d = {}
+    temb, cross = _trunk(d, cfg)
+    boc = tuple(cfg["block_out_channels"])
+    n = len(boc)
+    rc = list(reversed(boc))
+    nl = cfg["layers_per_block"] + 1
+    out = rc[0]
+    for i, t in enumerate(cfg["up_block_types"]):
+        prev, out = out, rc[i]
+        inc = rc[min(i + 1, n - 1)]
+        for j in range(nl):
+            skip = inc if j == nl - 1 else out
+            rin = prev if j == 0 else out
+            _resblock(d, f"up_blocks.{i}.resnets.{j}", rin + skip, out, temb)
+            if t.startswith("CrossAttn"):
+                _transformer(d, f"up_blocks.{i}.attentions.{j}", out, cross)
+        if i != n - 1:
+            _conv(d, f"up_blocks.{i}.upsamplers.0.conv", out, out, 3, 3)
+    _norm(d, "conv_norm_out", boc[0])
+    _conv(d, "conv_out", cfg["out_channels"], boc[0], 3, 3)
+    return d
+
+
+def controlnet_schema(config=None, conditioning_embedding_out_channels=(16, 32, 96, 256)):
+    cfg = dict(DEFAULT_CONFIG); cfg.update(config or {})
+    d = {}
+    _trunk(d, cfg)
+    boc = tuple(cfg["block_out_channels"])
+    k = 0
+    _conv(d, f"controlnet_down_blocks.{k}", boc[0], boc[0], 1, 1); k += 1
+    for i in range(len(boc)):
+        for _ in range(cfg["layers_per_block"]):
+            _conv(d, f"controlnet_down_blocks.{k}", boc[i], boc[i], 1, 1); k += 1
+        if i != len(boc) - 1:
+            _conv(d, f"controlnet_down_blocks.{k}", boc[i], boc[i], 1, 1); k += 1
+    _conv(d, "controlnet_mid_block", boc[-1], boc[-1], 1, 1)
+    ce = conditioning_embedding_out_channels
+    _conv(d, "controlnet_cond_embedding.conv_in", ce[0], 3, 3, 3)
+    for i in range(len(ce) - 1):
+        _conv(d, f"controlnet_cond_embedding.blocks.{2 * i}", ce[i], ce[i], 3, 3)
+        _conv(d, f"controlnet_cond_embedding.blocks.{2 * i + 1}", ce[i + 1], ce[i], 3, 3)
+    _conv(d, "controlnet_cond_embedding.conv_out", boc[0], ce[-1], 3, 3)
+    # FlowControlNetFirstFrameEncoder(c_in=320, channels=[320, 640, 1280]) -- svdxt_...norefine.py:130-146;
+    # expressed through block_out_channels so reduced test configs stay consistent with the trunk
+    cin = boc[0]
+    for i, ch in enumerate(boc[:3]):
+        _conv(d, f"flow_encoder.encoders.{i}.conv_in", ch, cin, 3, 3)
+        _conv(d, f"flow_encoder.zeroconvs.{i}", ch, ch, 1, 1)
+        cin = ch
+    return d
+
+
+def vae_decoder_schema(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, out_channels=3):
+    d = {}
+    boc = tuple(block_out_channels)
+    _conv(d, "decoder.conv_in", boc[-1], latent_channels, 3, 3)
+    for i in range(layers_per_block):
+        _resblock(d, f"decoder.mid_block.resnets.{i}", boc[-1], boc[-1], None)
+    a = "decoder.mid_block.attentions.0"
+    _norm(d, a + ".group_norm", boc[-1])
+    _attn(d, a, boc[-1], boc[-1], bias=True)
+    rc = list(reversed(boc))
+    out = rc[0]
+    for i in range(len(boc)):
+        prev, out = out, rc[i]
+        for j in range(layers_per_block + 1):
+            _resblock(d, f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else out, out, None)
+        if i != len(boc) - 1:
+            _conv(d, f"decoder.up_blocks.{i}.upsamplers.0.conv", out, out, 3, 3)
+    _norm(d, "decoder.conv_norm_out", boc[0])
+    _conv(d, "decoder.conv_out", out_channels, boc[0], 3, 3)
+    _conv(d, "decoder.time_conv_out", out_channels, out_channels, 3, 1, 1)
+    return d
+
+
+def synthetic_state_dict(schema, seed=0, device="cpu", dtype=torch.float16):
+    """Seeded random weights in the reference layout (default-init-like scales; zero-initialised reference
+    layers are random too, otherwise the adapter would contribute nothing -- SURVEY 8c)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for k, shape in schema.items():
+        if k.endswith("mix_factor"):
+            t = torch.full(shape, 0.5, device=device) + 0.3 * torch.randn(shape, generator=g, device=device)
+        elif len(shape) == 1:
+            is_norm_w = k.endswith(".weight")
+            t = 0.05 * torch.randn(shape, generator=g, device=device)
+            if is_norm_w:
+                t = t + 1.0
+        else:
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            t = (torch.rand(shape, generator=g, device=device) * 2 - 1) / math.sqrt(fan_in)
+        sd[k] = t.to(dtype)
+    return sd

@@ -1,0 +1,117 @@
+"""MI355X host mirror of ``AutoencoderKLTemporalDecoder.decode`` (diffusers==0.24.0
+models/autoencoder_kl_temporal_decoder.py), called by the reference at
+MOFA-Video-Traj/pipeline/pipeline.py:194-220 (``decode_latents``: /scaling_factor, chunks of
+``decode_chunk_size`` frames, each chunk decoded independently).  ``state_dict`` keys are the diffusers
+``decoder.*`` names.  The encoder half runs once per clip before the hot path and is out of scope.
+"""
+import math
+
+import torch
+
+from . import lib as L
+from . import ops
+from .blocks import Conv3x3, ConvT3, Ctx, GroupNorm, Linear, SpatioTemporalResBlock, Sub
+
+
+def _res(s):
+    return SpatioTemporalResBlock(s, eps=1e-6, temporal_eps=1e-5, switch=True)
+
+
+class _MidAttention:
+    """diffusers Attention(heads=1, dim_head=512, group norm 32 eps 1e-6, bias, residual_connection)."""
+
+    def __init__(self, s):
+        self.norm = GroupNorm(s.sub("group_norm"), 1e-6)
+        self.to_q, self.to_k, self.to_v = Linear(s.sub("to_q")), Linear(s.sub("to_k")), Linear(s.sub("to_v"))
+        self.to_out = Linear(s.sub("to_out.0"))
+        self.C = self.to_q.w.shape[0]
+
+    def __call__(self, x, nframes, S):
+        Cc = self.C
+        assert S % 64 == 0 and Cc % 64 == 0
+        h = self.norm(x, nframes, S)
+        q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
+        vt = ops.transpose_v(v, nframes, Cc // 64, S)                   # [nframes*C, S] = V^T per frame
+        o = torch.empty((nframes * S, Cc), dtype=torch.float16, device=x.device)
+        scale = 1.0 / math.sqrt(Cc)
+        for f in range(nframes):                                         # scores materialised per frame
+            rows = slice(f * S, (f + 1) * S)
+            p = ops.igemm(q[rows], k[rows].contiguous(), s_acc=scale)    # [S, S] = Q K^T / sqrt(d)
+            ops.softmax_rows_(p)
+            ops.igemm(p, vt[f * Cc:(f + 1) * Cc], out=o[rows])           # P V
+        return self.to_out(o, r1=x, s1=1.0)
+
+
+class TemporalDecoder:
+    def __init__(self, s, block_out_channels=(128, 256, 512, 512), layers_per_block=2):
+        self.conv_in = Conv3x3(s.sub("conv_in"))
+        self.in_ld = self.conv_in.w.shape[1] // 9
+        m = s.sub("mid_block")
+        self.mid_res = [_res(m.sub(f"resnets.{i}")) for i in range(layers_per_block)]
+        self.mid_attn = _MidAttention(m.sub("attentions.0"))
+        self.up_blocks = []
+        n = len(block_out_channels)
+        for i in range(n):
+            u = s.sub(f"up_blocks.{i}")
+            res = [_res(u.sub(f"resnets.{j}")) for j in range(layers_per_block + 1)]
+            up = Conv3x3(u.sub("upsamplers.0.conv"), up=2) if i != n - 1 else None
+            self.up_blocks.append((res, up))
+        self.conv_norm_out = GroupNorm(s.sub("conv_norm_out"), 1e-6)
+        self.conv_out = Conv3x3(s.sub("conv_out"), pad_n=True)          # 3 -> 4 output rows
+        self.time_conv_out = ConvT3(s.sub("time_conv_out"), pad_n=True)
+        self.out_channels = self.conv_out.n_real
+
+    def __call__(self, z_tokens, nframes, H, W):
+        c = Ctx(1, nframes)
+        x = self.conv_in(z_tokens, H, W)
+        x = self.mid_res[0](x, c, H, W)
+        x = self.mid_attn(x, nframes, H * W)
+        for r in self.mid_res[1:]:
+            x = r(x, c, H, W)
+        for res, up in self.up_blocks:
+            for r in res:
+                x = r(x, c, H, W)
+            if up is not None:
+                x = up(x, H, W)
+                H, W = H * 2, W * 2
+        x = self.conv_norm_out(x, nframes, H * W, silu=True)
+        kin = self.time_conv_out.w.shape[1] // 3                         # channel-padded width (64)
+        y = torch.zeros((x.shape[0], kin), dtype=torch.float16, device=x.device)
+        self.conv_out(x, H, W, out=y)
+        y = self.time_conv_out(y, nframes, H * W)                        # [n*H*W, 4]
+        return y, H, W
+
+
+class AutoencoderKLTemporalDecoder:
+    def __init__(self, state_dict, config=None, device="cuda"):
+        cfg = dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4,
+                   scaling_factor=0.18215, force_upcast=True)
+        cfg.update(config or {})
+        self.config = type("Cfg", (dict,), {"__getattr__": dict.__getitem__})(cfg)
+        self.device = torch.device(device)
+        self.dtype = torch.float16
+        self.decoder = TemporalDecoder(Sub(state_dict, "decoder.", device), tuple(cfg["block_out_channels"]),
+                                       cfg["layers_per_block"])
+
+    @classmethod
+    def from_module(cls, module, device="cuda"):
+        return cls(module.state_dict(), None, device)
+
+    def decode(self, z, num_frames=1, _prescale=1.0):
+        """z [n, 4, h, w] (n = batch*num_frames, one temporal group of num_frames) -> fp32 [n, 3, 8h, 8w]"""
+        n, Cz, h, w = z.shape
+        assert n == num_frames, "one clip chunk per call (reference decodes chunk by chunk, batch 1)"
+        zt = ops.nchw_to_tokens(z.to(self.device, torch.float32), ld=self.decoder.in_ld, scale=_prescale)
+        y, H, W = self.decoder(zt, n, h, w)
+        return ops.tokens_to_nchw(y, n, self.decoder.out_channels, H, W)
+
+
+def decode_latents(vae, latents, num_frames, decode_chunk_size=14):
+    """pipeline.py:194-220.  latents fp32 [1, T, 4, h, w] -> fp32 frames [1, 3, T, H, W]"""
+    lat = latents.flatten(0, 1)
+    frames = []
+    for i in range(0, lat.shape[0], decode_chunk_size):
+        chunk = lat[i:i + decode_chunk_size]          # 1/scaling_factor is applied inside the layout kernel
+        frames.append(vae.decode(chunk, num_frames=chunk.shape[0], _prescale=1.0 / vae.config.scaling_factor))
+    frames = torch.cat(frames, dim=0)
+    return frames.reshape(-1, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4).float()

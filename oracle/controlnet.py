@@ -107,7 +107,10 @@ class FlowControlNet(nn.Module):
             transformer_layers_per_block=transformer_layers_per_block, cross_attention_dim=cross_attention_dim,
             num_attention_heads=num_attention_heads[-1])
         # svdxt_...norefine.py:215-221
-        self.flow_encoder = FlowControlNetFirstFrameEncoder()
+        # reference: FlowControlNetFirstFrameEncoder() = (c_in=320, channels=[320,640,1280]); written through
+        # block_out_channels so reduced test configs stay consistent (identical at the default config)
+        self.flow_encoder = FlowControlNetFirstFrameEncoder(c_in=block_out_channels[0],
+                                                            channels=tuple(block_out_channels[:3]))
         self.controlnet_cond_embedding = FlowControlNetConditioningEmbeddingSVD(
             conditioning_embedding_channels=block_out_channels[0],
             block_out_channels=conditioning_embedding_out_channels, conditioning_channels=conditioning_channels)
