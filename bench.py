@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoised frames/sec, 25 f 576x1024 SVD + MOFA-Adapter, 25 denoise steps (+ VAE decode),
+on N MI355X (BASELINE.json metric; config[1] "MOFA-Video-Traj, 25-frame 576x1024, 25 steps, single trajectory
+hint").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one whole clip: adapter condition preparation + 25 denoise steps (ControlNet trunk + UNet + CFG/Euler)
++ chunked temporal-VAE decode, on synthetic inputs already resident in HBM.  Weights are seeded random in the
+reference checkpoint layout (no checkpoints offline), fp16 storage / fp32 accumulate -- the reference's precision.
+N > 1: one process per GPU; each rank denoises its own clip (independent clips, no data-path collective -> weak
+scaling); the barrier + max-over-ranks timing contract is kept.  Rank 0 prints ONE JSON line with the extra
+``roofline`` (dominant kernel = MFMA implicit-GEMM, timed per launch with HIP events on the launch stream during
+the timed region) and ``cpu_baseline`` (the CPU oracle on a bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T, H, W, STEPS, CHUNK = 25, 576, 1024, 25, 8
+CLIP_TFLOP = 5638.0          # single-adapter clip, reference schedule (adapter work per step)
+MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
+
+
+def synthetic_inputs(device, seed=42):
+    """one Gaussian-bump trajectory growing linearly to (+64, +32) px."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    h, w = H // 8, W // 8
+    lat = torch.randn(1, T, 4, h, w, generator=g)
+    il = torch.randn(1, 4, h, w, generator=g) / 0.18215
+    emb = torch.randn(1, 1, 1024, generator=g)
+    cond = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    ys = torch.arange(H, dtype=torch.float32).view(H, 1)
+    xs = torch.arange(W, dtype=torch.float32).view(1, W)
+    sig = 0.15 * min(H, W)
+    bump = torch.exp(-((xs - W / 2) ** 2 + (ys - H / 2) ** 2) / (2 * sig * sig))
+    flow = torch.zeros(1, T - 1, 2, H, W)
+    for i in range(T - 1):
+        f = (i + 1) / (T - 1)
+        flow[0, i, 0] = bump * 64.0 * f
+        flow[0, i, 1] = bump * 32.0 * f
+    return {k: v.to(device) for k, v in dict(latents=lat, image_latents=il, image_embeddings=emb, cond=cond,
+                                             flow=flow).items()}
+
+
+def build_pipeline(device, seed=0):
+    from mofa_video_amd import schema
+    from mofa_video_amd.adapter import FlowControlNet
+    from mofa_video_amd.pipeline import FlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    from mofa_video_amd.unet import UNetSpatioTemporalConditionControlNetModel
+    from mofa_video_amd.vae import AutoencoderKLTemporalDecoder
+    mods = []
+    for i, (cls, sch) in enumerate([(UNetSpatioTemporalConditionControlNetModel, schema.unet_schema()),
+                                    (FlowControlNet, schema.controlnet_schema()),
+                                    (AutoencoderKLTemporalDecoder, schema.vae_decoder_schema())]):
+        sd = schema.synthetic_state_dict(sch, seed=seed + i, device=device)
+        mods.append(cls(sd, None, device))
+        del sd
+        torch.cuda.empty_cache()
+    unet, cn, vae = mods
+    return FlowControlNetPipeline(vae=vae, unet=unet, controlnet=cn, scheduler=EulerDiscreteScheduler())
+
+
+def run_clip(pipe, inp):
+    out = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=H, width=W, num_frames=T,
+               num_inference_steps=STEPS, decode_chunk_size=CHUNK, latents=inp["latents"], output_type="pt",
+               image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"])
+    return out.frames
+
+
+def cpu_baseline():
+    """The CPU oracle (fp32 PyTorch restatement of the reference pipeline) on a bounded sample: ONE denoise step
+    (MOFA-Adapter/ControlNet + UNet, CFG batch 2) of the full SVD-XT architecture at 8 frames x 256x256
+    (BASELINE config[0] geometry, 6.43 TFLOP), converted to the metric's unit through the analytic work model
+    (225.5 TFLOP per denoised frame at config[1])."""
+    from oracle.controlnet import FlowControlNet
+    from oracle.unet import UNetSpatioTemporalConditionControlNetModel
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    with torch.device("meta"):
+        u, c = UNetSpatioTemporalConditionControlNetModel(), FlowControlNet()
+    u, c = u.to_empty(device="cpu"), c.to_empty(device="cpu")
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for m in (u, c):
+            for name, p in m.named_parameters():
+                if p.dim() > 1:
+                    fan = p[0].numel()
+                    p.uniform_(-fan ** -0.5, fan ** -0.5, generator=g)
+                elif name.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+    setup = time.time() - t0
+    Tc, Hc, Wc = 8, 256, 256
+    x = torch.randn(2, Tc, 8, Hc // 8, Wc // 8, generator=g)
+    emb = torch.randn(2, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 128.0, 0.02]] * 2)
+    cond = torch.rand(2, 3, Hc, Wc, generator=g)
+    flow = torch.randn(2, Tc - 1, 2, Hc, Wc, generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        dr, mr, _, _ = c(x, torch.tensor(1.0), emb, ids, controlnet_cond=cond, controlnet_flow=flow, return_dict=False)
+        u(x, torch.tensor(1.0), emb, down_block_additional_residuals=dr, mid_block_additional_residual=mr,
+          return_dict=False, added_time_ids=ids)
+    dt = time.time() - t0
+    sample_tflop = 6.43
+    cpu_tflops = sample_tflop / dt
+    fps = cpu_tflops / 225.5
+    return dict(value=fps, unit="denoised frames/sec", cores=cores, kind="port",
+                sample=(f"oracle (fp32 torch CPU, {cores} threads): one denoise step of the full SVD-XT UNet + MOFA "
+                        f"ControlNet at 8 f x 256x256 = {sample_tflop} TFLOP in {dt:.1f} s ({cpu_tflops:.3f} TFLOP/s; "
+                        f"model setup {setup:.0f} s untimed), scaled by 225.5 TFLOP per denoised frame at 25 f 576x1024"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from mofa_video_amd import lib, ops
+    lib.load()                                              # fails loudly without the HIP library
+    pipe = build_pipeline(dev, seed=0)
+    inp = synthetic_inputs(dev, seed=42 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_clip(pipe, inp)
+    timer = ops.LaunchTimer()
+    ops.TIMER = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frames = run_clip(pipe, inp)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    finite = bool(torch.isfinite(frames).all().item())
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        summ = timer.summary()
+        ig = summ.get("igemm_f16_kernel", dict(launches=1, seconds=1.0, flops=0.0))
+        avg_s = ig["seconds"] / max(ig["launches"], 1)
+        ach = ig["flops"] / ig["seconds"] / 1e12
+        at = summ.get("attn_spatial_kernel")
+        roofline = dict(kernel="igemm_f16_kernel", bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS,
+                        unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        launches_per_clip=ig["launches"] // max(args.steps, 1),
+                        avg_launch_us=round(avg_s * 1e6, 1),
+                        algorithmic_tflop_per_launch=round(ig["flops"] / max(ig["launches"], 1) / 1e12, 5),
+                        share_of_clip_time=round(ig["seconds"] / dt, 3))
+        if at:
+            roofline["attn_spatial_kernel"] = dict(achieved=round(at["flops"] / at["seconds"] / 1e12, 1), unit="TFLOP/s",
+                                                   frac=round(at["flops"] / at["seconds"] / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                                   share_of_clip_time=round(at["seconds"] / dt, 3))
+        value = T * args.steps * world / dt
+        line = {
+            "metric": "denoised frames/sec, 25f 576x1024 SVD+MOFA, 25 steps", "value": round(value, 4),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "MOFA-Video-Traj, 25-frame 576x1024, 25 denoise steps + temporal VAE decode "
+                                   "(chunk 8), single trajectory hint, SVD-XT UNet + MOFA-Adapter, CFG 1->3, "
+                                   "seeded random weights in the reference checkpoint layout",
+                       "num_frames": T, "height": H, "width": W, "num_inference_steps": STEPS,
+                       "decode_chunk_size": CHUNK, "step_definition": "one whole clip (adapter prep + 25 denoise "
+                       "steps + VAE decode)", "parallelism": f"{world} independent clip(s), one per GPU",
+                       "output_finite": finite,
+                       "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOP * args.steps / dt, 1)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -78,17 +78,20 @@ int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
  * base[token*ld + head*64 + d].  Replaces diffusers AttnProcessor2_0 / F.scaled_dot_product_attention
  * inside BasicTransformerBlock.attn1 (spatial) and TemporalBasicTransformerBlock.attn1 (temporal).
  * ---------------------------------------------------------------------------------------- */
-/* spatial self-attention, head_dim 64: batch = nframes, sequence = S tokens per frame.
- * vt is V transposed per (frame, head): vt[((frame*heads + head)*64 + d)*S + key]. */
+/* spatial self-attention, head_dim 64 or 128: batch = nframes, sequence = S tokens per frame.
+ * (The MOFA ControlNet trunk is built with heads (5,10,10,20) -- FlowControlNet calls super().__init__()
+ *  without arguments, svdxt_..._norefine.py:213 -> controlnet_sdv.py:180 -- so its 1280-channel level runs
+ *  10 heads x 128; the SVD-XT UNet runs 64 everywhere.)
+ * vt is V transposed per frame: vt[((frame*heads + head)*head_dim + d)*S + key] = [frame][C][S]. */
 int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out,
-                          int nframes, int heads, int S, int ldq, int ldk, int ldo, float scale,
+                          int nframes, int heads, int head_dim, int S, int ldq, int ldk, int ldo, float scale,
                           mofa_stream_t stream);
-/* [tokens][ld] column block (head-major, 64 wide) -> vt layout above */
-int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int heads, int S, int ldv, mofa_stream_t stream);
-/* temporal self-attention over T frames per (clip, pixel, head), head_dim 64, T <= 32.
+/* [tokens][ld] columns in blocks of 64 (ncb = C/64 blocks) -> vt layout above */
+int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int ncb, int S, int ldv, mofa_stream_t stream);
+/* temporal self-attention over T frames per (clip, pixel, head), head_dim 64 or 128, T <= 32.
  * token row of (clip b, frame t, pixel p) = (b*T + t)*HW + p. */
 int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out,
-                           int nclips, int T, int HW, int heads, int ld, int ldo, float scale,
+                           int nclips, int T, int HW, int heads, int head_dim, int ld, int ldo, float scale,
                            mofa_stream_t stream);
 /* in-place row softmax of an fp16 [rows][cols] matrix (VAE mid-block attention, 1 head x 512) */
 int mofa_softmax_rows_f16(void* x, int rows, int cols, int ld, mofa_stream_t stream);

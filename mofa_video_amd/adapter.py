@@ -42,8 +42,15 @@ class _CondEmbedding:
 
 
 class FlowControlNet:
+    # The reference FlowControlNet.__init__ calls ``super().__init__()`` WITHOUT arguments
+    # (svdxt_..._norefine.py:213), so whatever config.json says, its trunk is ControlNetSDVModel's default
+    # architecture (controlnet_sdv.py:158-183): in particular num_attention_heads = (5, 10, 10, 20), i.e. the
+    # 1280-channel level-2 transformers run 10 heads of dim 128 (the SVD-XT UNet runs (5, 10, 20, 20)).
+    TRUNK_HEADS = (5, 10, 10, 20)
+
     def __init__(self, state_dict, config=None, device="cuda", dtype=torch.float16):
         cfg = dict(DEFAULT_CONFIG)
+        cfg["num_attention_heads"] = self.TRUNK_HEADS
         cfg.update(config or {})
         self.config = _Config(cfg)
         self.device, self.dtype = torch.device(device), dtype

@@ -189,7 +189,9 @@ class SelfAttn:
         self.wqkv = s.dev(pack_linear(w))
         self.to_out = Linear(s.sub("to_out.0"))
         self.heads = heads
-        self.C = heads * 64
+        self.C = w.shape[0] // 3
+        self.head_dim = self.C // heads      # diffusers: attention_head_dim = out_channels // num_attention_heads
+        assert self.head_dim in (64, 128), f"unsupported head dim {self.head_dim}"
 
     def qkv(self, x):
         qkv = ops.igemm(x, self.wqkv)
@@ -234,14 +236,14 @@ class TransformerSpatioTemporal:
         h = self.proj_in(h)
         # --- spatial BasicTransformerBlock ---
         q, k, v = self.attn1.qkv(self.norm1(h))
-        a = ops.attn_spatial(q, k, v, N, self.heads, HW)
+        a = ops.attn_spatial(q, k, v, N, self.heads, HW, head_dim=self.attn1.head_dim)
         h = self.attn1.to_out(a, r1=h, s1=1.0, rowvec=v_sp, rv=(T * HW, 1, 1, BIG))      # + attn1 + attn2
         h = self.ff(self.norm3(h), r1=h, s1=1.0)                                          # x_spatial
         # --- TemporalBasicTransformerBlock on h + pos[t] ---
         pos_rv = (HW, 1, 1, T)
         f = self.ff_in(self.norm_in(h, rowvec=pos, rv_div=HW, rv_mod=T), r1=h, s1=1.0, rowvec=pos, rv=pos_rv)
         q, k, v = self.tattn1.qkv(self.tnorm1(f))
-        a = ops.attn_temporal(q, k, v, B, T, HW, self.heads)
+        a = ops.attn_temporal(q, k, v, B, T, HW, self.heads, head_dim=self.tattn1.head_dim)
         quirk = (T * HW, HW, HW, B) if c.time_context_hw_major else (T * HW, 1, 1, BIG)
         f = self.tattn1.to_out(a, r1=f, s1=1.0, rowvec=v_tm, rv=quirk)
         al = self.alpha

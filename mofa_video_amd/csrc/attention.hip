@@ -12,61 +12,75 @@
 //   one wave per sequence, VALU fp32.
 #include "common.h"
 
-#define ATT_KSTR 72   // K tile row stride (halves): 144 B, conflict-free ds_read_b128
 #define ATT_VSTR 68   // V^T tile row stride (halves): 136 B, conflict-free ds_read_b64
 #define ATT_TILE 64
 
+// D = head dim (64 or 128).  K tile row stride D+8 halves (144 / 272 B: conflict-free ds_read_b128).
+template <int D>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                               const f16* __restrict__ vt, f16* __restrict__ out,
                                                               int heads, int S, int ldq, int ldk, int ldo, float c) {
-    __shared__ __attribute__((aligned(16))) f16 sK[2][ATT_TILE * ATT_KSTR];
-    __shared__ __attribute__((aligned(16))) f16 sV[2][ATT_TILE * ATT_VSTR];
+    constexpr int ATT_KSTR = D + 8;
+    constexpr int KK = D / 16;       // MFMA k-steps of S^T
+    constexpr int DB = D / 32;       // 32-wide output d-blocks
+    constexpr int NCH = D / 32;      // 16-byte chunks per thread per tile (K and V^T each)
+    extern __shared__ __attribute__((aligned(16))) char smem_att[];
+    f16* sKb = (f16*)smem_att;                          // [2][64 * ATT_KSTR]
+    f16* sVb = sKb + 2 * ATT_TILE * ATT_KSTR;           // [2][D * ATT_VSTR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, frame = blockIdx.z;
     const int q0 = blockIdx.x * 128 + wave * 32;
 
-    const f16* kbase = k + (size_t)frame * S * ldk + head * 64;
-    const f16* vbase = vt + ((size_t)(frame * heads + head) * 64) * S;
+    const f16* kbase = k + (size_t)frame * S * ldk + head * D;
+    const f16* vbase = vt + ((size_t)(frame * heads + head) * D) * S;
 
     // Q fragments (B operand of S^T): lane (query l31, half lh) holds Q[q][16*kk + 8*lh .. +8)
-    f16x8 qf[4];
+    f16x8 qf[KK];
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     {
         const int qi = q0 + l31;
-        const f16* qp = q + ((size_t)frame * S + (qi < S ? qi : 0)) * ldq + head * 64 + lh * 8;
+        const f16* qp = q + ((size_t)frame * S + (qi < S ? qi : 0)) * ldq + head * D + lh * 8;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) qf[kk] = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
+        for (int kk = 0; kk < KK; ++kk) qf[kk] = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
     }
 
-    f32x16 o[2];
+    f32x16 o[DB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
 
-    // loader mapping: 64 rows x 8 chunks(16 B) per tile, 2 chunks per thread
-    const int lcol = tid & 7, lrow = tid >> 3;
-    f16x8 gk[2], gv[2];
+    // loader mapping: K tile = 64 keys x D/8 chunks(16 B); V^T tile = D rows x 8 chunks; NCH chunks per thread each
+    constexpr int CPR = D / 8;
+    f16x8 gk[NCH], gv[NCH];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = lrow + 32 * i;
-            const int key = k0 + row;
-            gk[i] = (key < S) ? *(const f16x8*)(kbase + (size_t)key * ldk + lcol * 8) : zero8;
-            const int kc = k0 + lcol * 8;  // V^T: row = d, 8 consecutive keys
-            gv[i] = (kc < S) ? *(const f16x8*)(vbase + (size_t)row * S + kc) : zero8;
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + 256 * i;
+            const int krow = cidx / CPR, kcol = cidx - krow * CPR;
+            const int key = k0 + krow;
+            gk[i] = (key < S) ? *(const f16x8*)(kbase + (size_t)key * ldk + kcol * 8) : zero8;
+            const int vrow = cidx >> 3, vcol = cidx & 7;   // V^T: row = d, 8 consecutive keys
+            const int kc = k0 + vcol * 8;
+            gv[i] = (kc < S) ? *(const f16x8*)(vbase + (size_t)vrow * S + kc) : zero8;
         }
     };
     auto store_tile = [&](int buf) {
+        f16* sK = sKb + buf * ATT_TILE * ATT_KSTR;
+        f16* sV = sVb + buf * D * ATT_VSTR;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = lrow + 32 * i;
-            *(f16x8*)&sK[buf][row * ATT_KSTR + lcol * 8] = gk[i];
+        for (int i = 0; i < NCH; ++i) {
+            const int cidx = tid + 256 * i;
+            const int krow = cidx / CPR, kcol = cidx - krow * CPR;
+            *(f16x8*)&sK[krow * ATT_KSTR + kcol * 8] = gk[i];
+            const int vrow = cidx >> 3, vcol = cidx & 7;
             f16x4 lo = {gv[i][0], gv[i][1], gv[i][2], gv[i][3]};
             f16x4 hi = {gv[i][4], gv[i][5], gv[i][6], gv[i][7]};
-            *(f16x4*)&sV[buf][row * ATT_VSTR + lcol * 8] = lo;
-            *(f16x4*)&sV[buf][row * ATT_VSTR + lcol * 8 + 4] = hi;
+            *(f16x4*)&sV[vrow * ATT_VSTR + vcol * 8] = lo;
+            *(f16x4*)&sV[vrow * ATT_VSTR + vcol * 8 + 4] = hi;
         }
     };
 
@@ -86,9 +100,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         for (int ts = 0; ts < 2; ++ts) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[ts][r] = 0.f;
-            const f16* kp = &sK[buf][(ts * 32 + l31) * ATT_KSTR + lh * 8];
+            const f16* kp = sKb + buf * ATT_TILE * ATT_KSTR + (ts * 32 + l31) * ATT_KSTR + lh * 8;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < KK; ++kk) {
                 const f16x8 kf = *(const f16x8*)(kp + kk * 16);
                 s[ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[ts], 0, 0, 0);
             }
@@ -120,13 +134,15 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             }
         l_run = l_run * alpha + psum;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
 
         // ---- O^T[d][q] += V^T[d][key] * P^T[key][q]; k-slot (8*lh + jj) of MFMA (ts,u) = key
         //      32*ts + 16*u + 4*lh + (jj&3) + 8*(jj>>2), identical for both operands ---------------
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const f16* vp = &sV[buf][(db * 32 + l31) * ATT_VSTR + 4 * lh];
+        for (int db = 0; db < DB; ++db) {
+            const f16* vp = sVb + buf * D * ATT_VSTR + (db * 32 + l31) * ATT_VSTR + 4 * lh;
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
@@ -145,9 +161,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     const float inv = 1.0f / l_tot;
     const int qi = q0 + l31;
     if (qi < S) {
-        f16* op = out + ((size_t)frame * S + qi) * ldo + head * 64;
+        f16* op = out + ((size_t)frame * S + qi) * ldo + head * D;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
                 f16x4 v;
@@ -158,20 +174,36 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     }
 }
 
-extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out, int nframes, int heads,
-                                     int S, int ldq, int ldk, int ldo, float scale, mofa_stream_t stream) {
-    if (!q || !k || !vt || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
-    if (S % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
+template <int D>
+static int launch_attn_spatial(const void* q, const void* k, const void* vt, void* out, int nframes, int heads, int S,
+                               int ldq, int ldk, int ldo, float c, hipStream_t st) {
+    constexpr int LDS = 2 * (ATT_TILE * (D + 8) + D * ATT_VSTR) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess)
+            return MOFA_ELAUNCH;
+        attr_set = true;
+    }
     dim3 grid(cdiv(S, 128), heads, nframes);
-    const float c = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)q, (const f16*)k,
-                       (const f16*)vt, (f16*)out, heads, S, ldq, ldk, ldo, c);
+    hipLaunchKernelGGL(attn_spatial_kernel<D>, grid, dim3(256), LDS, st, (const f16*)q, (const f16*)k, (const f16*)vt,
+                       (f16*)out, heads, S, ldq, ldk, ldo, c);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
 
+extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out, int nframes, int heads,
+                                     int head_dim, int S, int ldq, int ldk, int ldo, float scale, mofa_stream_t stream) {
+    if (!q || !k || !vt || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
+    if (S % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
+    const float c = scale * 1.4426950408889634f;
+    if (head_dim == 64) return launch_attn_spatial<64>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
+    if (head_dim == 128) return launch_attn_spatial<128>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
+    return MOFA_EINVAL;
+}
+
 // ---------------------------------------------------------------------------------------------------
-// V [tokens][ldv] column block (head*64 + d) -> V^T [(frame*heads + head)*64 + d][S]
+// V [tokens][ldv] columns c (64-column blocks) -> V^T [(frame*ncb + cb)*64 + d][S]  (= [frame][C][S], any head dim)
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_v_kernel(const f16* __restrict__ v, f16* __restrict__ vt, int heads,
                                                           int S, int ldv) {
@@ -217,49 +249,50 @@ extern "C" int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int he
 // Temporal attention: sequence = the T frames of one (clip, pixel, head).  One wave per sequence:
 // lane (i = lane&31, hf = lane>>5): query i, keys [16*hf, 16*hf+16), output dims [32*hf, 32*hf+32).
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
-                                                            const f16* __restrict__ v, f16* __restrict__ out,
-                                                            long long nseq, int T, int HW, int heads, int ld, int ldo,
-                                                            float scale) {
-    __shared__ __attribute__((aligned(16))) f16 sK[4][32 * 64];
-    __shared__ __attribute__((aligned(16))) f16 sV[4][32 * 64];
+template <int D, int WPB>
+__global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
+                                                                 const f16* __restrict__ v, f16* __restrict__ out,
+                                                                 long long nseq, int T, int HW, int heads, int ld, int ldo,
+                                                                 float scale) {
+    constexpr int DC = D / 8;       // 16-byte chunks per row
+    constexpr int DH = D / 2;       // output dims per lane half
+    __shared__ __attribute__((aligned(16))) f16 sK[WPB][32 * D];
+    __shared__ __attribute__((aligned(16))) f16 sV[WPB][32 * D];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long seq = (long long)blockIdx.x * 4 + wave;
+    const long long seq = (long long)blockIdx.x * WPB + wave;
     const bool active = seq < nseq;
     const int i = lane & 31, hf = lane >> 5;
 
     size_t base = 0;
+    int head = 0;
     if (active) {
-        const int head = (int)(seq % heads);
+        head = (int)(seq % heads);
         const long long bp = seq / heads;
         const int p = (int)(bp % HW);
         const int b = (int)(bp / HW);
-        base = ((size_t)b * T * HW + p);
-        base = base * (size_t)1;  // row of frame 0
-        // stage K and V rows of the T frames: T*8 chunks of 16 B each
-        for (int c = lane; c < T * 8; c += 64) {
-            const int t = c >> 3, cc = c & 7;
+        base = ((size_t)b * T * HW + p);   // token row of frame 0
+        for (int c = lane; c < T * DC; c += 64) {
+            const int t = c / DC, cc = c - t * DC;
             const size_t row = base + (size_t)t * HW;
-            *(f16x8*)&sK[wave][t * 64 + cc * 8] = *(const f16x8*)(k + row * ld + head * 64 + cc * 8);
-            *(f16x8*)&sV[wave][t * 64 + cc * 8] = *(const f16x8*)(v + row * ld + head * 64 + cc * 8);
+            *(f16x8*)&sK[wave][t * D + cc * 8] = *(const f16x8*)(k + row * ld + head * D + cc * 8);
+            *(f16x8*)&sV[wave][t * D + cc * 8] = *(const f16x8*)(v + row * ld + head * D + cc * 8);
         }
     }
     __syncthreads();
     if (!active) return;
-    const int head = (int)(seq % heads);
 
-    float qv[64];
+    float qv[D];
     if (i < T) {
-        const f16* qp = q + (base + (size_t)i * HW) * ld + head * 64;
+        const f16* qp = q + (base + (size_t)i * HW) * ld + head * D;
 #pragma unroll
-        for (int cidx = 0; cidx < 8; ++cidx) {
+        for (int cidx = 0; cidx < DC; ++cidx) {
             const f16x8 a = *(const f16x8*)(qp + cidx * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) qv[cidx * 8 + e] = (float)a[e] * scale;
         }
     } else {
 #pragma unroll
-        for (int e = 0; e < 64; ++e) qv[e] = 0.f;
+        for (int e = 0; e < D; ++e) qv[e] = 0.f;
     }
     float sc[16];
     float mx = -1e30f;
@@ -268,9 +301,9 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
         const int j = hf * 16 + jj;
         float acc = 0.f;
         if (j < T) {
-            const f16* kp = &sK[wave][j * 64];
+            const f16* kp = &sK[wave][j * D];
 #pragma unroll
-            for (int cidx = 0; cidx < 8; ++cidx) {
+            for (int cidx = 0; cidx < DC; ++cidx) {
                 const f16x8 a = *(const f16x8*)(kp + cidx * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc = fmaf(qv[cidx * 8 + e], (float)a[e], acc);
@@ -291,27 +324,27 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
 
-    float ov[32];
+    float ov[DH];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) ov[e] = 0.f;
+    for (int e = 0; e < DH; ++e) ov[e] = 0.f;
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const float other = __shfl_xor(sc[jj], 32, 64);
         const float p_lo = hf == 0 ? sc[jj] : other;   // key jj
         const float p_hi = hf == 0 ? other : sc[jj];   // key 16 + jj
         if (jj < T) {
-            const f16* vp = &sV[wave][jj * 64 + hf * 32];
+            const f16* vp = &sV[wave][jj * D + hf * DH];
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
+            for (int cidx = 0; cidx < DH / 8; ++cidx) {
                 const f16x8 a = *(const f16x8*)(vp + cidx * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[cidx * 8 + e] = fmaf(p_lo, (float)a[e], ov[cidx * 8 + e]);
             }
         }
         if (16 + jj < T) {
-            const f16* vp = &sV[wave][(16 + jj) * 64 + hf * 32];
+            const f16* vp = &sV[wave][(16 + jj) * D + hf * DH];
 #pragma unroll
-            for (int cidx = 0; cidx < 4; ++cidx) {
+            for (int cidx = 0; cidx < DH / 8; ++cidx) {
                 const f16x8 a = *(const f16x8*)(vp + cidx * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ov[cidx * 8 + e] = fmaf(p_hi, (float)a[e], ov[cidx * 8 + e]);
@@ -319,9 +352,9 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
         }
     }
     if (i < T) {
-        f16* op = out + (base + (size_t)i * HW) * ldo + head * 64 + hf * 32;
+        f16* op = out + (base + (size_t)i * HW) * ldo + head * D + hf * DH;
 #pragma unroll
-        for (int cidx = 0; cidx < 4; ++cidx) {
+        for (int cidx = 0; cidx < DH / 8; ++cidx) {
             f16x8 a;
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] = (f16)(ov[cidx * 8 + e] * inv);
@@ -331,12 +364,19 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 }
 
 extern "C" int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out, int nclips, int T, int HW,
-                                      int heads, int ld, int ldo, float scale, mofa_stream_t stream) {
+                                      int heads, int head_dim, int ld, int ldo, float scale, mofa_stream_t stream) {
     if (!q || !k || !v || !out || nclips <= 0 || T <= 0 || T > 32 || HW <= 0 || heads <= 0) return MOFA_EINVAL;
     if (ld % 8 != 0 || ldo % 8 != 0) return MOFA_EINVAL;
     const long long nseq = (long long)nclips * HW * heads;
-    hipLaunchKernelGGL(attn_temporal_kernel, dim3(cdiv(nseq, 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)q,
-                       (const f16*)k, (const f16*)v, (f16*)out, nseq, T, HW, heads, ld, ldo, scale);
+    if (head_dim == 64) {
+        hipLaunchKernelGGL((attn_temporal_kernel<64, 4>), dim3(cdiv(nseq, 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, T, HW, heads, ld, ldo, scale);
+    } else if (head_dim == 128) {
+        hipLaunchKernelGGL((attn_temporal_kernel<128, 2>), dim3(cdiv(nseq, 2)), dim3(128), 0, (hipStream_t)stream,
+                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, T, HW, heads, ld, ldo, scale);
+    } else {
+        return MOFA_EINVAL;
+    }
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

@@ -39,9 +39,9 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 PROTOTYPES = {
     "mofa_version": [],
     "mofa_igemm_f16": [C.POINTER(IgemmArgs), _P],
-    "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
-    "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_softmax_rows_f16": [_P, _I, _I, _I, _P],
     "mofa_gn_nparts": [_I, _I],
     "mofa_gn_partial_f16": [_P, _P, _I, _I, _I, _I, _P],

@@ -15,6 +15,39 @@ F16 = torch.float16
 F32 = torch.float32
 
 
+class LaunchTimer:
+    """Optional per-launch HIP-event timing on the launch stream (bench.py's roofline leg).  When
+    ``ops.TIMER`` is set, every timed entry point brackets its launch with two events recorded on the
+    current stream and logs the launch's algorithmic work; ``summary()`` reads the events after a sync."""
+
+    def __init__(self):
+        self.rec = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, e0, flops=0.0, nbytes=0.0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append((name, e0, e1, flops, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, fl, nb in self.rec:
+            d = out.setdefault(name, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["seconds"] += e0.elapsed_time(e1) * 1e-3
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+TIMER = None
+
+
 def _ld(t):
     assert t.dim() == 2 and t.stride(1) == 1, "token-major 2-D tensor with unit channel stride expected"
     return t.stride(0)
@@ -93,7 +126,10 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     a.rv_div, a.rv_mul, a.rv_mod_in, a.rv_mod_out = rv
     a.act = act
     a.s_acc, a.s1, a.s2 = s_acc, s1, s2
+    t0 = TIMER.start() if TIMER is not None else None
     L.check(lib.mofa_igemm_f16(C.byref(a), L.stream_ptr()), "mofa_igemm_f16")
+    if t0 is not None:
+        TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot)
     return out
 
 
@@ -130,27 +166,32 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
 
 
 # ---- attention -----------------------------------------------------------------------------------------
-def attn_spatial(q, k, v, nframes, heads, S, scale=0.125, out=None):
-    """q/k/v: [nframes*S, heads*64] column blocks (views allowed)."""
+def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None):
+    """q/k/v: [nframes*S, heads*head_dim] column blocks (views allowed); scale defaults to head_dim**-0.5."""
     lib = L.load()
-    Cc = heads * 64
+    Cc = heads * head_dim
+    scale = head_dim ** -0.5 if scale is None else scale
     st = L.stream_ptr()
-    vt = torch.empty((nframes * heads * 64, S), dtype=F16, device=q.device)
-    L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, heads, S, _ld(v), st), "mofa_transpose_v_f16")
+    vt = torch.empty((nframes * Cc, S), dtype=F16, device=q.device)
+    L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, Cc // 64, S, _ld(v), st), "mofa_transpose_v_f16")
     if out is None:
         out = torch.empty((nframes * S, Cc), dtype=F16, device=q.device)
-    L.check(lib.mofa_attn_spatial_f16(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(out), nframes, heads, S, _ld(q), _ld(k),
-                                      _ld(out), scale, st), "mofa_attn_spatial_f16")
+    t0 = TIMER.start() if TIMER is not None else None
+    L.check(lib.mofa_attn_spatial_f16(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(out), nframes, heads, head_dim, S, _ld(q),
+                                      _ld(k), _ld(out), scale, st), "mofa_attn_spatial_f16")
+    if t0 is not None:
+        TIMER.stop("attn_spatial_kernel", t0, flops=4.0 * S * S * Cc * nframes)
     return out
 
 
-def attn_temporal(q, k, v, nclips, T, HW, heads, scale=0.125, out=None):
+def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=None):
     lib = L.load()
     assert _ld(q) == _ld(k) == _ld(v)
+    scale = head_dim ** -0.5 if scale is None else scale
     if out is None:
-        out = torch.empty((nclips * T * HW, heads * 64), dtype=F16, device=q.device)
-    L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, T, HW, heads, _ld(q), _ld(out),
-                                       scale, L.stream_ptr()), "mofa_attn_temporal_f16")
+        out = torch.empty((nclips * T * HW, heads * head_dim), dtype=F16, device=q.device)
+    L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, T, HW, heads, head_dim, _ld(q),
+                                       _ld(out), scale, L.stream_ptr()), "mofa_attn_temporal_f16")
     return out
 
 
@@ -160,10 +201,11 @@ def softmax_rows_(x):
     return x
 
 
-def transpose_v(v, nframes, heads, S):
+def transpose_v(v, nframes, ncb, S):
+    """v [nframes*S, ncb*64] -> V^T [nframes*ncb*64, S]"""
     lib = L.load()
-    vt = torch.empty((nframes * heads * 64, S), dtype=F16, device=v.device)
-    L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, heads, S, _ld(v), L.stream_ptr()),
+    vt = torch.empty((nframes * ncb * 64, S), dtype=F16, device=v.device)
+    L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, ncb, S, _ld(v), L.stream_ptr()),
             "mofa_transpose_v_f16")
     return vt
 

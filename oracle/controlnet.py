@@ -14,7 +14,11 @@ import torch.nn.functional as F
 
 from .blocks import Timesteps, TimestepEmbedding, UNetMidBlockSpatioTemporal, get_down_block
 from .softsplat import softsplat
-from .unet import SVD_XT_HEADS
+
+# FlowControlNet.__init__ calls ``super().__init__()`` with NO arguments (svdxt_..._norefine.py:213): the trunk is
+# always ControlNetSDVModel's default architecture, whose num_attention_heads default is (5, 10, 10, 20)
+# (controlnet_sdv.py:180) -- not the SVD-XT UNet's (5, 10, 20, 20).  Level 2 therefore runs 10 heads x 128.
+CONTROLNET_TRUNK_HEADS = (5, 10, 10, 20)
 
 
 class FlowControlNetConditioningEmbeddingSVD(nn.Module):
@@ -68,7 +72,7 @@ class FlowControlNet(nn.Module):
                  down_block_types=("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",),
                  block_out_channels=(320, 640, 1280, 1280), addition_time_embed_dim=256,
                  projection_class_embeddings_input_dim=768, layers_per_block=2, cross_attention_dim=1024,
-                 transformer_layers_per_block=1, num_attention_heads=SVD_XT_HEADS, num_frames=25,
+                 transformer_layers_per_block=1, num_attention_heads=CONTROLNET_TRUNK_HEADS, num_frames=25,
                  conditioning_channels=3, conditioning_embedding_out_channels=(16, 32, 96, 256)):
         super().__init__()
         self.config = dict(in_channels=in_channels, block_out_channels=tuple(block_out_channels),

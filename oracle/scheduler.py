@@ -30,7 +30,7 @@ class EulerDiscreteScheduler:
         self.alphas = 1.0 - self.betas
         self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
         self.use_karras_sigmas = cfg["use_karras_sigmas"]
-        sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)[::-1].copy()
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()[::-1].copy()
         if self.use_karras_sigmas:
             sigmas = self._convert_to_karras(sigmas, n)
         sigmas = torch.from_numpy(sigmas).to(torch.float32)
@@ -85,7 +85,7 @@ class EulerDiscreteScheduler:
             timesteps = (np.arange(n, 0, -step_ratio)).round().copy().astype(np.float32) - 1
         else:
             raise ValueError(sp)
-        sigmas = np.array(((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5)
+        sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         log_sigmas = np.log(sigmas)
         if self.config["interpolation_type"] == "linear":
             sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)

@@ -7,6 +7,8 @@ import torch
 from mofa_video_amd import schema
 
 TINY = dict(block_out_channels=(64, 128, 256, 256), num_attention_heads=(1, 2, 4, 4), cross_attention_dim=128)
+# the reference ControlNet trunk uses heads (5,10,10,20) -> head dim 128 at level 2; mirrored here (256 / 2)
+TINY_CN = dict(TINY, num_attention_heads=(1, 2, 2, 4))
 TINY_VAE = dict(block_out_channels=(64, 64, 128, 128))
 
 
@@ -15,18 +17,19 @@ def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-12)).item()
 
 
-def oracle_models(cfg=None, seed=0, vae_cfg=None):
+def oracle_models(cfg=None, seed=0, vae_cfg=None, cn_cfg=None):
     """returns (oracle_unet, oracle_controlnet, oracle_vae, sd_unet, sd_ctrl, sd_vae) with fp16-valued weights"""
     from oracle.controlnet import FlowControlNet
     from oracle.unet import UNetSpatioTemporalConditionControlNetModel
     from oracle.vae import AutoencoderKLTemporalDecoder
     kw = cfg or {}
+    ckw = cn_cfg if cn_cfg is not None else kw
     sdu = schema.synthetic_state_dict(schema.unet_schema(cfg), seed=seed)
-    sdc = schema.synthetic_state_dict(schema.controlnet_schema(cfg), seed=seed + 1)
+    sdc = schema.synthetic_state_dict(schema.controlnet_schema(cn_cfg if cn_cfg is not None else cfg), seed=seed + 1)
     vkw = vae_cfg or {}
     sdv = schema.synthetic_state_dict(schema.vae_decoder_schema(**vkw), seed=seed + 2)
     u = UNetSpatioTemporalConditionControlNetModel(**kw)
-    c = FlowControlNet(**kw)
+    c = FlowControlNet(**ckw)
     v = AutoencoderKLTemporalDecoder(**vkw)
     u.load_state_dict({k: t.float() for k, t in sdu.items()})
     c.load_state_dict({k: t.float() for k, t in sdc.items()})

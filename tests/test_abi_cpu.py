@@ -1,0 +1,99 @@
+"""CPU tests of the boundary and host logic: the C-ABI library loads and exports every symbol include/mofa_hip.h
+declares (no compute calls without a GPU), the ctypes prototypes cover exactly that set, the product package
+never reaches into oracle/, and the host-side weight repacking / geometry helpers behave."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "mofa_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(mofa_\w+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mofa_video_amd import _build, lib
+    _build.build()                                   # hipcc cross-compiles for gfx950 without a GPU
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(dll, s), f"libmofa_hip.so does not export {s}"
+    assert sorted(lib.PROTOTYPES) == syms, set(lib.PROTOTYPES) ^ set(syms)
+    assert lib.load().mofa_version() >= 100
+
+
+def test_igemm_args_struct_layout_matches_header():
+    from mofa_video_amd.lib import IgemmArgs
+    # 7 pointers + 21 int32 + 3 float = 56 + 84 + 12 = 152 bytes, no padding surprises
+    assert ctypes.sizeof(IgemmArgs) == 152
+    assert IgemmArgs.M.offset == 56 and IgemmArgs.s_acc.offset == 140
+
+
+def test_argument_validation_without_gpu():
+    """entry points reject bad arguments before touching the device"""
+    from mofa_video_amd import lib
+    l = lib.load()
+    a = lib.IgemmArgs()
+    assert l.mofa_igemm_f16(ctypes.byref(a), None) == -22          # null pointers
+    assert l.mofa_attn_spatial_f16(None, None, None, None, 1, 1, 64, 8, 8, 8, 8, 0.125, None) == -22
+    assert l.mofa_gn_nparts(9216, 320) == 36 * 2
+    assert l.mofa_softsplat_ws_bytes(24, 72, 128) > 24 * 72 * 128 * 44
+
+
+def test_product_does_not_import_oracle_or_reference():
+    pkg = os.path.join(ROOT, "mofa_video_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "/root/reference" not in src, f
+    for f in ("bench.py",):
+        src = open(os.path.join(ROOT, f)).read()
+        assert "/root/reference" not in src
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from mofa_video_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.MofaHipError):
+        lib.load()
+
+
+def test_weight_packing():
+    from mofa_video_amd.weights import interleave_geglu, pack_conv3d_t3, pack_conv3x3, pack_linear, pad_rows
+    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = pack_conv3x3(w)                                # Cin 3 -> 64
+    assert p.shape == (2, 9 * 64) and p.dtype == torch.float16
+    for tap in range(9):
+        ky, kx = divmod(tap, 3)
+        assert torch.equal(p[:, tap * 64:tap * 64 + 3].float(), w[:, :, ky, kx])
+        assert p[:, tap * 64 + 3:(tap + 1) * 64].abs().max() == 0
+    w3 = torch.randn(4, 64, 3, 1, 1)
+    p3 = pack_conv3d_t3(w3)
+    assert torch.equal(p3[:, 64:128], w3[:, :, 1, 0, 0].half())
+    assert pack_linear(torch.randn(8, 100)).shape == (8, 128)
+    assert pad_rows(torch.ones(3, 5)).shape == (4, 5)
+    Ch = 64
+    wg = torch.arange(2 * Ch, dtype=torch.float32).reshape(2 * Ch, 1)
+    wi, bi = interleave_geglu(wg, wg[:, 0])
+    assert wi[:32, 0].tolist() == list(range(32)) and wi[32:64, 0].tolist() == list(range(Ch, Ch + 32))
+    assert torch.equal(wi[:, 0], bi)
+
+
+def test_conv_geometry():
+    from mofa_video_amd import ops
+    g = ops.conv3x3_geom(72, 128, stride=2)
+    assert (g.Hout, g.Wout) == (36, 64)
+    g = ops.conv3x3_geom(9, 16, stride=2)
+    assert (g.Hout, g.Wout) == (5, 8)
+    g = ops.conv3x3_geom(36, 64, up=2)
+    assert (g.Hout, g.Wout) == (72, 128)

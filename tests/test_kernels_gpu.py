@@ -141,13 +141,14 @@ def test_igemm_rejects_bad_args(ops):
 # ---------------------------------------------------------------------------------------------------------
 # attention
 # ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("S,heads,frames", [(200, 3, 2), (64, 1, 1), (16, 2, 3), (1024, 5, 2)])
-def test_attn_spatial(ops, S, heads, frames):
-    Cc = heads * 64
+@pytest.mark.parametrize("S,heads,frames,hd", [(200, 3, 2, 64), (64, 1, 1, 64), (16, 2, 3, 64), (1024, 5, 2, 64),
+                                                 (200, 2, 2, 128), (576, 10, 1, 128), (16, 1, 2, 128)])
+def test_attn_spatial(ops, S, heads, frames, hd):
+    Cc = heads * hd
     qkv = _h(frames * S, 3 * Cc, seed=20)
     d = qkv.to(DEV)
-    out = ops.attn_spatial(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S)
-    q, k, v = [t.float().reshape(frames, S, heads, 64).transpose(1, 2) for t in qkv.split(Cc, dim=1)]
+    out = ops.attn_spatial(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S, head_dim=hd)
+    q, k, v = [t.float().reshape(frames, S, heads, hd).transpose(1, 2) for t in qkv.split(Cc, dim=1)]
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(frames * S, Cc)
     _close(out, ref, tol=4e-3, what="attn spatial")
 
@@ -164,13 +165,14 @@ def test_attn_spatial_online_softmax_rescale(ops):
     _close(out, ref, tol=4e-3, what="attn spatial rescale")
 
 
-@pytest.mark.parametrize("T,HW,heads,clips", [(25, 37, 2, 2), (8, 16, 1, 2), (32, 5, 3, 1), (1, 9, 1, 1)])
-def test_attn_temporal(ops, T, HW, heads, clips):
-    Cc = heads * 64
+@pytest.mark.parametrize("T,HW,heads,clips,hd", [(25, 37, 2, 2, 64), (8, 16, 1, 2, 64), (32, 5, 3, 1, 64), (1, 9, 1, 1, 64),
+                                                 (25, 19, 2, 2, 128), (32, 3, 1, 1, 128)])
+def test_attn_temporal(ops, T, HW, heads, clips, hd):
+    Cc = heads * hd
     qkv = _h(clips * T * HW, 3 * Cc, seed=22)
     d = qkv.to(DEV)
-    out = ops.attn_temporal(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], clips, T, HW, heads)
-    q, k, v = [t.float().reshape(clips, T, HW, heads, 64).permute(0, 2, 3, 1, 4) for t in qkv.split(Cc, dim=1)]
+    out = ops.attn_temporal(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], clips, T, HW, heads, head_dim=hd)
+    q, k, v = [t.float().reshape(clips, T, HW, heads, hd).permute(0, 2, 3, 1, 4) for t in qkv.split(Cc, dim=1)]
     ref = F.scaled_dot_product_attention(q, k, v)  # [clips, HW, heads, T, 64]
     ref = ref.permute(0, 3, 1, 2, 4).reshape(clips * T * HW, Cc)
     _close(out, ref, tol=2e-3, what="attn temporal")

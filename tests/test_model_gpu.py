@@ -7,7 +7,7 @@ Stated fp16 tolerance (fp16 storage + fp32 accumulate vs fp32 oracle): relative 
 import pytest
 import torch
 
-from helpers import TINY, TINY_VAE, oracle_models, rel_l2, synthetic_inputs
+from helpers import TINY, TINY_CN, TINY_VAE, oracle_models, rel_l2, synthetic_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -19,9 +19,9 @@ def models():
     from mofa_video_amd.adapter import FlowControlNet
     from mofa_video_amd.unet import UNetSpatioTemporalConditionControlNetModel
     from mofa_video_amd.vae import AutoencoderKLTemporalDecoder
-    ou, oc, ov, sdu, sdc, sdv = oracle_models(TINY, seed=0, vae_cfg=TINY_VAE)
+    ou, oc, ov, sdu, sdc, sdv = oracle_models(TINY, seed=0, vae_cfg=TINY_VAE, cn_cfg=TINY_CN)
     hu = UNetSpatioTemporalConditionControlNetModel(sdu, TINY, DEV)
-    hc = FlowControlNet(sdc, TINY, DEV)
+    hc = FlowControlNet(sdc, TINY_CN, DEV)
     hv = AutoencoderKLTemporalDecoder(sdv, TINY_VAE, DEV)
     return ou, oc, ov, hu, hc, hv
 

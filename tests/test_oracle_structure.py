@@ -1,0 +1,117 @@
+"""CPU tests: structural checksums and self-consistency of the oracle (the reference holds no tests of its own,
+SURVEY F5, so these are the known answers we can state independently), and the oracle softsplat against the
+reference's own kernel compiled for the host (oracle/_ref)."""
+import pytest
+import torch
+
+from oracle.softsplat import softsplat, softsplat_sum
+
+
+def _nparams(m):
+    return sum(p.numel() for p in m.parameters())
+
+
+def test_parameter_count_checksums():
+    from oracle.controlnet import FlowControlNet
+    from oracle.unet import UNetSpatioTemporalConditionControlNetModel
+    from oracle.vae import AutoencoderKLTemporalDecoder
+    with torch.device("meta"):
+        u, c, v = UNetSpatioTemporalConditionControlNetModel(), FlowControlNet(), AutoencoderKLTemporalDecoder()
+    assert _nparams(u) == 1_524_623_082          # public SVD-XT UNet size
+    assert _nparams(c) == 694_314_017            # trunk 669 455 377 + 13 zero convs + cond CNN + flow encoder
+    assert _nparams(v) == 63_579_183             # temporal decoder
+    assert len(c.controlnet_down_blocks) == 12
+
+
+def test_schema_matches_oracle_and_checksums():
+    from mofa_video_amd import schema
+    import math
+    assert sum(math.prod(s) for s in schema.unet_schema().values()) == 1_524_623_082
+    assert sum(math.prod(s) for s in schema.controlnet_schema().values()) == 694_314_017
+    assert sum(math.prod(s) for s in schema.vae_decoder_schema().values()) == 63_579_183
+
+
+def test_residual_quirk_multiplicity():
+    """unet_..._controlnet.py:434-459: residual i is added once per remaining down block."""
+    from mofa_video_amd.unet import residual_multiplicity
+    assert residual_multiplicity([4, 7, 10, 12], 12) == [4, 4, 4, 4, 3, 3, 3, 2, 2, 2, 1, 1]
+    # and the oracle forward really does that: with zero weights everywhere except identity-like skips this is
+    # checked numerically through the reference-generated golden (test_oracle_golden.py)
+
+
+# ---- softsplat ------------------------------------------------------------------------------------------------
+def test_softsplat_zero_flow_and_integer_shift():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 3, 6, 7, generator=g)
+    out = softsplat(x, torch.zeros(2, 2, 6, 7), None, "avg")
+    assert torch.allclose(out, x / (1 + 1e-7), rtol=1e-6, atol=1e-7)
+    flow = torch.zeros(2, 2, 6, 7)
+    flow[:, 0] = 2.0
+    flow[:, 1] = -1.0
+    out = softsplat(x, flow, None, "avg")
+    ref = torch.zeros_like(x)
+    ref[:, :, 0:5, 2:7] = x[:, :, 1:6, 0:5]
+    assert torch.allclose(out, ref, rtol=1e-6, atol=1e-7)         # targets that receive nothing are exactly 0
+    assert (out[:, :, 5, :] == 0).all() and (out[:, :, :, :2] == 0).all()
+
+
+def test_softsplat_nonfinite_and_out_of_bounds():
+    x = torch.ones(1, 1, 4, 4)
+    flow = torch.zeros(1, 2, 4, 4)
+    flow[0, 0, 0, 0] = float("nan")
+    flow[0, 1, 1, 1] = float("inf")
+    flow[0, :, 2, 2] = torch.tensor([100.0, 0.0])
+    s = softsplat_sum(x, flow)
+    assert s[0, 0, 0, 0] == 0 and s[0, 0, 1, 1] == 0 and s[0, 0, 2, 2] == 0
+    assert s.sum() == 13.0
+
+
+def test_softsplat_modes_assertions():
+    x, f = torch.zeros(1, 1, 2, 2), torch.zeros(1, 2, 2, 2)
+    with pytest.raises(AssertionError):
+        softsplat(x, f, x, "avg")
+    with pytest.raises(AssertionError):
+        softsplat(x, f, None, "soft")
+    with pytest.raises(AssertionError):
+        softsplat(x, f, None, "bogus")
+
+
+def test_softsplat_vs_reference_kernel_host_build():
+    """oracle/_ref = the reference's CUDA kernel text compiled for the host (oracle/build_ref.py)."""
+    from oracle import softsplat_ref
+    if not softsplat_ref.available():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    g = torch.Generator().manual_seed(3)
+    for (N, C, H, W, mag) in [(2, 5, 12, 20, 3.0), (1, 33, 9, 16, 0.4), (3, 2, 18, 32, 12.0)]:
+        x = torch.randn(N, C, H, W, generator=g)
+        f = torch.randn(N, 2, H, W, generator=g) * mag
+        f[0, :, 0, 0] = float("nan")
+        f[-1, 0, 1, 1] = float("-inf")
+        f[0, :, 2, 2] = torch.tensor([3.0, -2.0])
+        f[0, :, 3, 3] = torch.tensor([-1000.0, 4.5])
+        a = softsplat_ref.softsplat_out_ref(x, f)
+        b = softsplat_sum(x, f)
+        assert torch.allclose(a, b, rtol=1e-5, atol=2e-6), (a - b).abs().max()
+        assert torch.allclose(softsplat_ref.softsplat_avg_ref(x, f), softsplat(x, f, None, "avg"), rtol=1e-5, atol=2e-6)
+
+
+def test_time_context_quirk_is_pixel_parity():
+    """diffusers 0.24.0 hw-major context: token row r = b*hw + s receives the context of batch r mod B."""
+    from oracle.blocks import TransformerSpatioTemporalModel
+    torch.manual_seed(0)
+    m = TransformerSpatioTemporalModel(1, 64, in_channels=64, cross_attention_dim=64).eval()
+    B, T, h, w = 2, 3, 2, 4
+    x = torch.randn(B * T, 64, h, w)
+    ctx = torch.randn(B * T, 1, 64)
+    ctx[:T] = ctx[0]
+    ctx[T:] = ctx[T]
+    ioi = torch.zeros(B, T)
+    with torch.no_grad():
+        y_quirk = m(x, ctx, ioi)
+        m.time_context_hw_major = False
+        y_fixed = m(x, ctx, ioi)
+    d = (y_quirk - y_fixed).abs().amax(dim=(1,))                   # [B*T, h, w]
+    flat = d.reshape(B, T, h * w)
+    # with B = 2: batch 0 differs at odd pixels, batch 1 at even pixels
+    assert (flat[0, :, 0::2] < 1e-6).all() and (flat[0, :, 1::2] > 1e-6).all()
+    assert (flat[1, :, 1::2] < 1e-6).all() and (flat[1, :, 0::2] > 1e-6).all()
