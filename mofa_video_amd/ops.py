@@ -28,10 +28,25 @@ class LaunchTimer:
         e.record()
         return e
 
-    def stop(self, name, e0, flops=0.0, nbytes=0.0):
+    def stop(self, name, e0, flops=0.0, nbytes=0.0, tag=None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
         self.rec.append((name, e0, e1, flops, nbytes))
+        if tag is not None:
+            self.tags.append((tag, len(self.rec) - 1))
+
+    tags = []
+
+    def by_tag(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, i in self.tags:
+            _, e0, e1, fl, _ = self.rec[i]
+            d = out.setdefault(tag, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += fl
+        return out
 
     def summary(self):
         torch.cuda.synchronize()
@@ -129,7 +144,8 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     t0 = TIMER.start() if TIMER is not None else None
     L.check(lib.mofa_igemm_f16(C.byref(a), L.stream_ptr()), "mofa_igemm_f16")
     if t0 is not None:
-        TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot)
+        TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot,
+                   tag=(geom.mode, geom.stride, geom.up, M, N, Ktot, act))
     return out
 
 
