@@ -107,36 +107,46 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                 s[ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[ts], 0, 0, 0);
             }
         }
-        // ---- mask + online softmax (per-lane query row; the two halves hold disjoint key subsets) ----
-        float mx = -1e30f;
+        // ---- mask (tail tile only) + online softmax (per-lane query row; the two halves hold disjoint keys) ----
+        if (__builtin_amdgcn_readfirstlane(k0 + ATT_TILE > S)) {
+            asm volatile("; tail tile" ::: "memory");   // keep this a real (wave-uniform) branch, not 64 selects per tile
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + ts * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key >= S) s[ts][r] = -1e30f;
+                }
+        }
+        float mx = s[0][0];
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + ts * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (key >= S) s[ts][r] = -1e30f;
-                mx = fmaxf(mx, s[ts][r]);
-            }
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ts][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        // the running max changes in few tiles once it has settled: rescale O only then (alpha == 1 exactly otherwise)
+        if (__any(mx > m_run)) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        const float mc = m_run * c;
         float psum = 0.f;
         f16x8 pf[2][2];
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(fmaf(s[ts][r], c, -mc));
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[ts][r], c, -mc));   // raw v_exp_f32: arguments are <= 0
                 psum += p;
                 pf[ts][r >> 3][r & 7] = (f16)p;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int db = 0; db < DB; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        l_run += psum;
 
         // ---- O^T[d][q] += V^T[d][key] * P^T[key][q]; k-slot (8*lh + jj) of MFMA (ts,u) = key
         //      32*ts + 16*u + 4*lh + (jj&3) + 8*(jj>>2), identical for both operands ---------------
