@@ -10,8 +10,10 @@ hint").
 One "step" = one whole clip: adapter condition preparation + 25 denoise steps (ControlNet trunk + UNet + CFG/Euler)
 + chunked temporal-VAE decode, on synthetic inputs already resident in HBM.  Weights are seeded random in the
 reference checkpoint layout (no checkpoints offline), fp16 storage / fp32 accumulate -- the reference's precision.
-N > 1: one process per GPU; each rank denoises its own clip (independent clips, no data-path collective -> weak
-scaling); the barrier + max-over-ranks timing contract is kept.  Rank 0 prints ONE JSON line with the extra
+N > 1 (one process per GPU): default ``--mode shard`` partitions ONE clip over the ranks -- 2-way CFG x N/2 frame
+shards with RCCL exchanges only at the temporal ops (mofa_video_amd/parallel.py; strong scaling) -- and
+``--mode replicas`` runs one independent clip per rank (weak scaling).  The barrier + max-over-ranks timing contract
+is kept in both.  Rank 0 prints ONE JSON line with the extra
 ``roofline`` (dominant kernel = MFMA implicit-GEMM, timed per launch with HIP events on the launch stream during
 the timed region) and ``cpu_baseline`` (the CPU oracle on a bounded sample) objects.
 """
@@ -151,6 +153,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["shard", "replicas"], default="shard",
+                    help="N > 1: 'shard' = ONE clip per step partitioned over the ranks (2-way CFG x N/2 frame shards, "
+                         "RCCL exchanges at the temporal ops; strong scaling) or 'replicas' = one independent clip per "
+                         "rank (no data-path collective; weak scaling)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,7 +176,24 @@ def main():
     from mofa_video_amd import lib, ops
     lib.load()                                              # fails loudly without the HIP library
     pipe = build_pipeline(dev, seed=0)
-    inp = synthetic_inputs(dev, seed=42 + rank)
+    mode = args.mode if world > 1 else "single"
+    mode_note = ""
+    if mode == "shard":
+        # every rank must see the same clip; partition = mofa_video_amd/parallel.py
+        from mofa_video_amd.parallel import FrameParallel, Layout, TorchComm
+        try:
+            if world % 2 != 0:
+                raise ValueError("shard mode needs an even number of ranks (2-way CFG split)")
+            comm = TorchComm(lambda r: Layout(world, r, T))
+            pipe.parallel = FrameParallel(Layout(world, rank, T), comm)
+            probe = torch.ones(4, device=dev, dtype=torch.float64)          # exercise the collectives once
+            comm.all_reduce_sum(probe, pipe.parallel.lay.frame_group)
+            comm.all_gather(probe, pipe.parallel.lay.pair_group)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            pipe.parallel = None
+            mode, mode_note = "replicas", f" (shard mode unavailable: {type(e).__name__}: {e})"
+    inp = synthetic_inputs(dev, seed=42 + (rank if mode == "replicas" else 0))
 
     def barrier():
         torch.cuda.synchronize()
@@ -189,7 +212,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
-    finite = bool(torch.isfinite(frames).all().item())
+    if isinstance(frames, list):                            # shard mode: the VAE chunks this rank decoded
+        finite = all(bool(torch.isfinite(f).all().item()) for _, f in frames)
+    else:
+        finite = bool(torch.isfinite(frames).all().item())
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -211,20 +237,26 @@ def main():
             roofline["attn_spatial_kernel"] = dict(achieved=round(at["flops"] / at["seconds"] / 1e12, 1), unit="TFLOP/s",
                                                    frac=round(at["flops"] / at["seconds"] / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                                    share_of_clip_time=round(at["seconds"] / dt, 3))
-        value = T * args.steps * world / dt
+        clips = args.steps * (world if mode == "replicas" else 1)
+        value = T * clips / dt
+        par_desc = {"single": "1 GPU", "replicas": f"{world} independent clips, one per GPU, no data-path collective",
+                    "shard": f"one clip over {world} GPUs: 2-way CFG x {max(world // 2, 1)}-way frame shards; RCCL "
+                             "all-reduce (temporal GroupNorm sums), halo p2p (temporal convs), all-gather (temporal "
+                             "attention K|V, CFG pair, final latents); VAE chunks round-robin"}[mode] + mode_note
         line = {
             "metric": "denoised frames/sec, 25f 576x1024 SVD+MOFA, 25 steps", "value": round(value, 4),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong" if mode == "shard" else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "MOFA-Video-Traj, 25-frame 576x1024, 25 denoise steps + temporal VAE decode "
                                    "(chunk 8), single trajectory hint, SVD-XT UNet + MOFA-Adapter, CFG 1->3, "
                                    "seeded random weights in the reference checkpoint layout",
                        "num_frames": T, "height": H, "width": W, "num_inference_steps": STEPS,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip (adapter prep + 25 denoise "
-                       "steps + VAE decode)", "parallelism": f"{world} independent clip(s), one per GPU",
+                       "steps + VAE decode)", "parallelism": par_desc,
                        "output_finite": finite,
-                       "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOP * args.steps / dt, 1)},
+                       "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOP * clips / dt / world, 1)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

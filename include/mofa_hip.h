@@ -64,7 +64,8 @@ typedef struct mofa_igemm_args {
     int32_t mode;       /* MOFA_MODE_*                                                       */
     /* MOFA_MODE_CONV3X3: rows are (img, oy, ox); pad 1; stride 1|2; up = 1|2 (nearest)      */
     int32_t Hin, Win, Hout, Wout, stride, up;
-    /* MOFA_MODE_CONVT3: rows are (frame, pixel); frames grouped in clips of T               */
+    /* MOFA_MODE_CONVT3: rows are (frame, pixel); frames grouped in clips of T; T = 0: no     */
+    /* clipping at clip ends (the caller placed halo frames before/after the rows)           */
     int32_t T, HW;
     int32_t rv_div, rv_mul, rv_mod_in, rv_mod_out;
     int32_t act;        /* MOFA_ACT_*                                                        */
@@ -89,10 +90,12 @@ int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* ou
 /* [tokens][ld] columns in blocks of 64 (ncb = C/64 blocks) -> vt layout above */
 int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int ncb, int S, int ldv, mofa_stream_t stream);
 /* temporal self-attention over T frames per (clip, pixel, head), head_dim 64 or 128, T <= 32.
- * token row of (clip b, frame t, pixel p) = (b*T + t)*HW + p. */
+ * k/v: token row of (clip b, frame t, pixel p) = (b*T + t)*HW + p, leading dim ldkv.
+ * q/out: Tq <= T query frames, row (b*Tq + i)*HW + p (Tq < T when a clip's frames are sharded over ranks and the
+ * keys/values were all-gathered; Tq == T otherwise). */
 int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out,
-                           int nclips, int T, int HW, int heads, int head_dim, int ld, int ldo, float scale,
-                           mofa_stream_t stream);
+                           int nclips, int Tq, int T, int HW, int heads, int head_dim, int ld, int ldkv, int ldo,
+                           float scale, mofa_stream_t stream);
 /* in-place row softmax of an fp16 [rows][cols] matrix (VAE mid-block attention, 1 head x 512) */
 int mofa_softmax_rows_f16(void* x, int rows, int cols, int ld, mofa_stream_t stream);
 
@@ -109,6 +112,12 @@ int mofa_gn_partial_f16(const void* x, float* part, int nframes, int HW, int C, 
 /* frames_per_stat = 1 (spatial) or T (temporal); writes scale/shift fp32 [nframes][C] */
 int mofa_gn_finalize(const float* part, const float* gamma, const float* beta, float* scale, float* shift,
                      int nframes, int HW, int C, int frames_per_stat, float eps, mofa_stream_t stream);
+/* split form for frame-sharded clips: partials -> fp64 [nstat][32][2] (sum, sum of squares); the caller all-reduces
+ * them over the ranks holding the clip's other frames, then finalizes with the global per-group element count */
+int mofa_gn_reduce(const float* part, double* sums, int nframes, int HW, int C, int frames_per_stat, mofa_stream_t stream);
+int mofa_gn_finalize_sums(const double* sums, const float* gamma, const float* beta, float* scale, float* shift,
+                          int nframes, int C, int frames_per_stat, double count_per_group, float eps,
+                          mofa_stream_t stream);
 /* y = x*scale[frame][c] + shift[frame][c]; optional SiLU */
 int mofa_affine_act_f16(const void* x, const float* scale, const float* shift, void* y,
                         int nframes, int HW, int C, int ldx, int ldy, int silu, mofa_stream_t stream);

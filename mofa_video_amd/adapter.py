@@ -86,9 +86,10 @@ class FlowControlNet:
         return cls(module.state_dict(), getattr(module, "config", None), device)
 
     # -- timestep-invariant adapter work (svdxt_...norefine.py:297-319) -------------------------------------
-    def prepare_condition(self, controlnet_cond, controlnet_flow):
+    def prepare_condition(self, controlnet_cond, controlnet_flow, frames=None):
         """controlnet_cond [1,3,H,W]; controlnet_flow [1,T-1,2,H,W] -> list of 4 token-major fp16 tensors
-        [T*h_l*w_l, C_l]: frame 0 = the first-frame feature, frames 1.. = its forward-splat by flow 0->i."""
+        [T*h_l*w_l, C_l]: frame 0 = the first-frame feature, frames 1.. = its forward-splat by flow 0->i.
+        frames = (f0, f1): only that frame range (a rank's shard of the clip)."""
         cond = controlnet_cond.to(self.device, torch.float32)
         flow = controlnet_flow.to(self.device, torch.float32)
         assert cond.shape[0] == 1 and flow.shape[0] == 1, "one clip per call (both CFG halves share it)"
@@ -101,26 +102,46 @@ class FlowControlNet:
             e = enc(e, h, w, act=L.ACT_SILU)
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
             feats.append((zc(e) if zc is not None else e, h, w))
-        fl = flow[0].contiguous()                                           # [T-1, 2, H, W]
+        T = flow.shape[1] + 1
+        f0, f1 = frames if frames is not None else (0, T)
+        w0 = max(f0, 1)                                                     # first warped frame of the range
+        fl = flow[0, w0 - 1:f1 - 1].contiguous() if f1 > w0 else None       # flows 0 -> i for i in [w0, f1)
         warped = []
         for (ft, h, w) in feats:
             s = H // h
-            fs = ops.flow_downscale(fl, s)                                  # F.interpolate(nearest, 1/s) / s
-            wr = ops.softsplat_avg_tokens(ft, fs, h, w)                     # [(T-1)*h*w, C]
-            allf = torch.empty((ft.shape[0] + wr.shape[0], ft.shape[1]), dtype=torch.float16, device=self.device)
-            ops.copy2d(ft, allf[:ft.shape[0]])
-            ops.copy2d(wr, allf[ft.shape[0]:])
+            hw = h * w
+            allf = torch.empty(((f1 - f0) * hw, ft.shape[1]), dtype=torch.float16, device=self.device)
+            off = 0
+            if f0 == 0:
+                ops.copy2d(ft, allf[:hw])
+                off = hw
+            if fl is not None:
+                fs = ops.flow_downscale(fl, s)                              # F.interpolate(nearest, 1/s) / s
+                wr = ops.softsplat_avg_tokens(ft, fs, h, w)                 # [(f1-w0)*h*w, C]
+                ops.copy2d(wr, allf[off:])
             warped.append(allf)
         return warped
 
-    def make_ctx(self, timestep, encoder_hidden_states, added_time_ids, B, T, base=None):
+    def make_ctx(self, timestep, encoder_hidden_states, added_time_ids, B, T, base=None, half=None, par=None):
+        """B, T = LOCAL batch / frame counts.  half: global CFG-half index when this rank computes one half only
+        (encoder_hidden_states / added_time_ids are then still the global 2-row tensors); par: FrameParallel."""
         c = base if base is not None else Ctx(B, T)
         ts = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
         ts = ts.expand(B).contiguous() if ts.numel() == 1 else ts.contiguous()
-        c.temb_act = self.time(ts, added_time_ids.to(self.device, torch.float32).contiguous())
+        ids = added_time_ids.to(self.device, torch.float32)
+        if half is not None:
+            ids = ids[half:half + B]
+        c.temb_act = self.time(ts, ids.contiguous())
         if c.ctx16 is None:
-            e = encoder_hidden_states.to(self.device, torch.float32).reshape(B, -1).contiguous()
-            c.ctx16 = ops.cast_f32_to_f16(e)
+            e = encoder_hidden_states.to(self.device, torch.float32)
+            e = e.reshape(e.shape[0], -1).contiguous()
+            if half is not None:
+                c.ctx16_all = ops.cast_f32_to_f16(e)
+                c.ctx16 = c.ctx16_all[half:half + B].contiguous()
+                c.half = half
+            else:
+                c.ctx16 = ops.cast_f32_to_f16(e)
+        c.par = par
         return c
 
     def _add_warped(self, sample, warped, B):

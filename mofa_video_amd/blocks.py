@@ -54,6 +54,9 @@ class Ctx:
         self.ctx16 = None         # fp16 [B, cross_dim] image embedding (first frame's == every frame's)
         self.cache = {}           # timestep-invariant per-layer vectors (cross-attention, frame-position emb)
         self.time_context_hw_major = True
+        self.par = None           # parallel.FrameParallel when this rank holds only frames [f0, f1) of the clip
+        self.ctx16_all = None     # fp16 [B_global, cross_dim]: both CFG halves' embeddings (temporal-context quirk)
+        self.half = 0             # global CFG-half index of local batch row 0
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -161,15 +164,33 @@ class SpatioTemporalResBlock:
         h = self.norm2(h, N, HW, silu=True)
         xs = self.shortcut(x) if self.shortcut is not None else x
         xs = self.conv2(h, H, W, r1=xs, s1=1.0)                          # ResnetBlock2D output
-        g = self.tnorm1(xs, N, HW, frames_per_stat=T, silu=True)
+        par = c.par
+        if par is None:
+            g = self.tnorm1(xs, N, HW, frames_per_stat=T, silu=True)
+            if self.ttemb is not None:
+                tv = ops.cast_f16_to_f32(self.ttemb(c.temb_act))
+                g = self.tconv1(g, T, HW, rowvec=tv, **rv)
+            else:
+                g = self.tconv1(g, T, HW)
+            g = self.tnorm2(g, N, HW, frames_per_stat=T, silu=True)
+            # alpha*xs + (1-alpha)*(xs + conv) = xs + (1-alpha)*conv
+            return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0)
+        # ---- frames of the clip sharded over ranks (one CFG half per rank): GroupNorm statistics are all-reduced,
+        #      the (3,1,1) convs read one halo frame from each neighbour shard (zeros at the clip ends) ----
+        assert c.B == 1
+        M = T * HW
+        gn = dict(frames_per_stat=T, silu=True, reduce_fn=par.reduce_gn, frames_total=par.T_full)
+        g = ops.group_norm(xs, self.tnorm1.g, self.tnorm1.b, N, HW, self.tnorm1.eps, **gn)
+        ext = par.halo(g, HW)
+        kw = dict(geom=ops.convt3_geom(0, HW), M=M)
         if self.ttemb is not None:
             tv = ops.cast_f16_to_f32(self.ttemb(c.temb_act))
-            g = self.tconv1(g, T, HW, rowvec=tv, **rv)
+            g = ops.igemm(ext[HW:], self.tconv1.w, self.tconv1.b, rowvec=tv, **rv, **kw)
         else:
-            g = self.tconv1(g, T, HW)
-        g = self.tnorm2(g, N, HW, frames_per_stat=T, silu=True)
-        # alpha*xs + (1-alpha)*(xs + conv) = xs + (1-alpha)*conv
-        return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0)
+            g = ops.igemm(ext[HW:], self.tconv1.w, self.tconv1.b, **kw)
+        g = ops.group_norm(g, self.tnorm2.g, self.tnorm2.b, N, HW, self.tnorm2.eps, **gn)
+        ext = par.halo(g, HW)
+        return ops.igemm(ext[HW:], self.tconv2.w, self.tconv2.b, s_acc=1.0 - self.alpha, r1=xs, s1=1.0, **kw)
 
 
 class CrossAttnVec:
@@ -224,9 +245,11 @@ class TransformerSpatioTemporal:
         key = ("xf", self.uid)
         if key not in c.cache:
             dev = self.proj_in.w.device
-            tpos = ops.timestep_embedding(torch.arange(c.T, dtype=torch.float32, device=dev), self.C)
+            f0 = c.par.f0 if c.par is not None else 0
+            tpos = ops.timestep_embedding(torch.arange(f0, f0 + c.T, dtype=torch.float32, device=dev), self.C)
             e = self.pos2(self.pos1(ops.cast_f32_to_f16(tpos), act=L.ACT_SILU))
-            c.cache[key] = (self.attn2(c.ctx16), self.tattn2(c.ctx16), ops.cast_f16_to_f32(e))
+            v_tm = self.tattn2(c.ctx16_all if c.ctx16_all is not None else c.ctx16)
+            c.cache[key] = (self.attn2(c.ctx16), v_tm, ops.cast_f16_to_f32(e))
         return c.cache[key]
 
     def __call__(self, x, c, H, W):
@@ -243,9 +266,28 @@ class TransformerSpatioTemporal:
         pos_rv = (HW, 1, 1, T)
         f = self.ff_in(self.norm_in(h, rowvec=pos, rv_div=HW, rv_mod=T), r1=h, s1=1.0, rowvec=pos, rv=pos_rv)
         q, k, v = self.tattn1.qkv(self.tnorm1(f))
-        a = ops.attn_temporal(q, k, v, B, T, HW, self.heads, head_dim=self.tattn1.head_dim)
-        quirk = (T * HW, HW, HW, B) if c.time_context_hw_major else (T * HW, 1, 1, BIG)
-        f = self.tattn1.to_out(a, r1=f, s1=1.0, rowvec=v_tm, rv=quirk)
+        if c.par is None:
+            a = ops.attn_temporal(q, k, v, B, T, HW, self.heads, head_dim=self.tattn1.head_dim)
+        else:   # this rank holds T of the clip's T_full frames: all-gather K|V along the frame axis
+            Cc = self.C
+            kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
+            ops.copy2d(k, kv[:, :Cc])
+            ops.copy2d(v, kv[:, Cc:])
+            kv = c.par.gather_frames(kv, HW)
+            a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, c.par.T_full, HW, self.heads,
+                                  head_dim=self.tattn1.head_dim, Tq=T)
+        # temporal cross-attention row vector.  diffusers 0.24.0 quirk: token row (b, s) of the GLOBAL batch takes the
+        # context of batch (b*HW + s) mod B_global; v_tm has one row per global batch element.
+        Bg = v_tm.shape[0]
+        if not c.time_context_hw_major:
+            quirk, tab = (T * HW, 1, 1, BIG), (v_tm if Bg == B else v_tm[c.half:c.half + B].contiguous())
+        elif Bg == B:
+            quirk, tab = (T * HW, HW, HW, B), v_tm
+        else:   # one half per rank: local b = 0 is global batch c.half -> rotate the table by (half*HW) mod Bg
+            rot = (c.half * HW) % Bg
+            tab = torch.cat([v_tm[rot:], v_tm[:rot]], 0).contiguous() if rot else v_tm
+            quirk = (T * HW, 0, HW, Bg)
+        f = self.tattn1.to_out(a, r1=f, s1=1.0, rowvec=tab, rv=quirk)
         al = self.alpha
         m = self.tff(self.tnorm3(f), s_acc=1.0 - al, r1=f, s1=1.0 - al, r2=h, s2=al)      # AlphaBlender
         return self.proj_out(m, r1=x, s1=1.0)

@@ -262,8 +262,10 @@ extern "C" int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int he
 template <int D, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                  const f16* __restrict__ v, f16* __restrict__ out,
-                                                                 long long nseq, int T, int HW, int heads, int ld, int ldo,
-                                                                 float scale) {
+                                                                 long long nseq, int Tq, int T, int HW, int heads, int ld,
+                                                                 int ldkv, int ldo, float scale) {
+    // Tq query frames (rows of q/out, clip stride Tq*HW), T key/value frames (rows of k/v, clip stride T*HW):
+    // Tq < T when the clip's frames are sharded over ranks and K/V were all-gathered.
     constexpr int DC = D / 8;       // 16-byte chunks per row
     constexpr int DH = D / 2;       // output dims per lane half
     __shared__ __attribute__((aligned(16))) f16 sK[WPB][32 * D];
@@ -273,27 +275,28 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
     const bool active = seq < nseq;
     const int i = lane & 31, hf = lane >> 5;
 
-    size_t base = 0;
+    size_t base = 0, qbase = 0;
     int head = 0;
     if (active) {
         head = (int)(seq % heads);
         const long long bp = seq / heads;
         const int p = (int)(bp % HW);
         const int b = (int)(bp / HW);
-        base = ((size_t)b * T * HW + p);   // token row of frame 0
+        base = ((size_t)b * T * HW + p);    // k/v token row of frame 0
+        qbase = ((size_t)b * Tq * HW + p);  // q/out token row of frame 0
         for (int c = lane; c < T * DC; c += 64) {
             const int t = c / DC, cc = c - t * DC;
             const size_t row = base + (size_t)t * HW;
-            *(f16x8*)&sK[wave][t * D + cc * 8] = *(const f16x8*)(k + row * ld + head * D + cc * 8);
-            *(f16x8*)&sV[wave][t * D + cc * 8] = *(const f16x8*)(v + row * ld + head * D + cc * 8);
+            *(f16x8*)&sK[wave][t * D + cc * 8] = *(const f16x8*)(k + row * ldkv + head * D + cc * 8);
+            *(f16x8*)&sV[wave][t * D + cc * 8] = *(const f16x8*)(v + row * ldkv + head * D + cc * 8);
         }
     }
     __syncthreads();
     if (!active) return;
 
     float qv[D];
-    if (i < T) {
-        const f16* qp = q + (base + (size_t)i * HW) * ld + head * D;
+    if (i < Tq) {
+        const f16* qp = q + (qbase + (size_t)i * HW) * ld + head * D;
 #pragma unroll
         for (int cidx = 0; cidx < DC; ++cidx) {
             const f16x8 a = *(const f16x8*)(qp + cidx * 8);
@@ -361,8 +364,8 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
             }
         }
     }
-    if (i < T) {
-        f16* op = out + (base + (size_t)i * HW) * ldo + head * D + hf * DH;
+    if (i < Tq) {
+        f16* op = out + (qbase + (size_t)i * HW) * ldo + head * D + hf * DH;
 #pragma unroll
         for (int cidx = 0; cidx < DH / 8; ++cidx) {
             f16x8 a;
@@ -373,17 +376,19 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
     }
 }
 
-extern "C" int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out, int nclips, int T, int HW,
-                                      int heads, int head_dim, int ld, int ldo, float scale, mofa_stream_t stream) {
-    if (!q || !k || !v || !out || nclips <= 0 || T <= 0 || T > 32 || HW <= 0 || heads <= 0) return MOFA_EINVAL;
-    if (ld % 8 != 0 || ldo % 8 != 0) return MOFA_EINVAL;
+extern "C" int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out, int nclips, int Tq, int T,
+                                      int HW, int heads, int head_dim, int ld, int ldkv, int ldo, float scale,
+                                      mofa_stream_t stream) {
+    if (!q || !k || !v || !out || nclips <= 0 || T <= 0 || T > 32 || Tq <= 0 || Tq > T || HW <= 0 || heads <= 0)
+        return MOFA_EINVAL;
+    if (ld % 8 != 0 || ldkv % 8 != 0 || ldo % 8 != 0) return MOFA_EINVAL;
     const long long nseq = (long long)nclips * HW * heads;
     if (head_dim == 64) {
         hipLaunchKernelGGL((attn_temporal_kernel<64, 4>), dim3(cdiv(nseq, 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, T, HW, heads, ld, ldo, scale);
+                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, Tq, T, HW, heads, ld, ldkv, ldo, scale);
     } else if (head_dim == 128) {
         hipLaunchKernelGGL((attn_temporal_kernel<128, 2>), dim3(cdiv(nseq, 2)), dim3(128), 0, (hipStream_t)stream,
-                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, T, HW, heads, ld, ldo, scale);
+                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, Tq, T, HW, heads, ld, ldkv, ldo, scale);
     } else {
         return MOFA_EINVAL;
     }

@@ -41,7 +41,7 @@ __device__ __forceinline__ RowGeo make_geo(const mofa_igemm_args& a, int m) {
         const int img = m / hw, rem = m - img * hw;
         g.img = img; g.oy = rem / a.Wout; g.ox = rem - g.oy * a.Wout;
     } else if (a.mode == MOFA_MODE_CONVT3) {
-        g.oy = (m / a.HW) % a.T;
+        g.oy = a.T > 0 ? (m / a.HW) % a.T : 0;
     }
     return g;
 }
@@ -61,7 +61,7 @@ __device__ __forceinline__ const f16* x_src(const mofa_igemm_args& a, const RowG
         return x + ((size_t)(g.img * a.Hin + iy) * a.Win + ix) * a.ldx;
     } else {  // MOFA_MODE_CONVT3
         const int tt = g.oy + tap - 1;
-        if (tt < 0 || tt >= a.T) return nullptr;
+        if (a.T > 0 && (tt < 0 || tt >= a.T)) return nullptr;   // T == 0: unclipped, caller supplies halo frames
         return x + ((size_t)g.m + (size_t)(tap - 1) * a.HW) * a.ldx;
     }
 }
@@ -450,7 +450,8 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if ((a->stride != 1 && a->stride != 2) || (a->up != 1 && a->up != 2)) return MOFA_EINVAL;
         if (a->M % (a->Hout * a->Wout) != 0) return MOFA_EINVAL;
     }
-    if (a->mode == MOFA_MODE_CONVT3 && (a->T <= 0 || a->HW <= 0 || a->M % (a->T * a->HW) != 0)) return MOFA_EINVAL;
+    if (a->mode == MOFA_MODE_CONVT3 && (a->T < 0 || a->HW <= 0 || (a->T > 0 && a->M % (a->T * a->HW) != 0)))
+        return MOFA_EINVAL;
     if (a->rowvec && (a->rv_div <= 0 || a->rv_mod_in <= 0 || a->rv_mod_out <= 0)) return MOFA_EINVAL;
     if (a->act == MOFA_ACT_GEGLU_PAIR && (a->N % 64 != 0 || a->r1 || a->r2 || a->rowvec)) return MOFA_EINVAL;
     if (a->ldx % 8 != 0 || a->ldo % 4 != 0) return MOFA_EINVAL;

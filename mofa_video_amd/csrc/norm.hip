@@ -133,6 +133,78 @@ extern "C" int mofa_gn_finalize(const float* part, const float* gamma, const flo
     return MOFA_OK;
 }
 
+// ---- split form for frame-sharded clips: local partials -> fp64 sums per (stat, group); the caller all-reduces the
+//      sums over the ranks that hold the clip's other frames, then finalizes with the GLOBAL element count ----------
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const float* __restrict__ part, double* __restrict__ sums, int fps,
+                                                        int nparts) {
+    __shared__ double dS[8][32], dQ[8][32];
+    const int tid = threadIdx.x, g = tid & 31, l8 = tid >> 5;
+    const int stat = blockIdx.x;
+    const int total = fps * nparts;
+    double a = 0.0, b = 0.0;
+    const float* p0 = part + (size_t)stat * fps * nparts * 64;
+    for (int i = l8; i < total; i += 8) {
+        a += (double)p0[(size_t)i * 64 + g * 2];
+        b += (double)p0[(size_t)i * 64 + g * 2 + 1];
+    }
+    dS[l8][g] = a;
+    dQ[l8][g] = b;
+    __syncthreads();
+    if (tid < 32) {
+        double s = 0.0, q = 0.0;
+        for (int r = 0; r < 8; ++r) { s += dS[r][tid]; q += dQ[r][tid]; }
+        sums[((size_t)stat * 32 + tid) * 2] = s;
+        sums[((size_t)stat * 32 + tid) * 2 + 1] = q;
+    }
+}
+extern "C" int mofa_gn_reduce(const float* part, double* sums, int nframes, int HW, int C, int frames_per_stat,
+                              mofa_stream_t stream) {
+    if (!part || !sums || nframes <= 0 || frames_per_stat <= 0 || nframes % frames_per_stat != 0 || C % 32 != 0)
+        return MOFA_EINVAL;
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(nframes / frames_per_stat), dim3(256), 0, (hipStream_t)stream, part, sums,
+                       frames_per_stat, mofa_gn_nparts(HW, C));
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_sums_kernel(const double* __restrict__ sums,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ scale,
+                                                               float* __restrict__ shift, int C, int fps, double cnt,
+                                                               float eps) {
+    __shared__ float sMean[32], sRstd[32];
+    const int tid = threadIdx.x, stat = blockIdx.x;
+    if (tid < 32) {
+        const double s = sums[((size_t)stat * 32 + tid) * 2], q = sums[((size_t)stat * 32 + tid) * 2 + 1];
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        sMean[tid] = (float)mean;
+        sRstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / 32;
+    for (int idx = tid; idx < fps * C; idx += 256) {
+        const int f = idx / C, c = idx - f * C;
+        const int gg = c / cpg;
+        const float sc = sRstd[gg] * gamma[c];
+        const size_t o = ((size_t)stat * fps + f) * C + c;
+        scale[o] = sc;
+        shift[o] = beta[c] - sMean[gg] * sc;
+    }
+}
+extern "C" int mofa_gn_finalize_sums(const double* sums, const float* gamma, const float* beta, float* scale,
+                                     float* shift, int nframes, int C, int frames_per_stat, double count_per_group,
+                                     float eps, mofa_stream_t stream) {
+    if (!sums || !gamma || !beta || !scale || !shift || nframes <= 0 || frames_per_stat <= 0 ||
+        nframes % frames_per_stat != 0 || C % 32 != 0 || count_per_group <= 0)
+        return MOFA_EINVAL;
+    hipLaunchKernelGGL(gn_finalize_sums_kernel, dim3(nframes / frames_per_stat), dim3(256), 0, (hipStream_t)stream, sums,
+                       gamma, beta, scale, shift, C, frames_per_stat, count_per_group, eps);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
 __global__ __launch_bounds__(256) void affine_act_kernel(const f16* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, f16* __restrict__ y,
                                                          long long nvec, int HW, int C, int ldx, int ldy, int silu) {

@@ -41,11 +41,13 @@ PROTOTYPES = {
     "mofa_igemm_f16": [C.POINTER(IgemmArgs), _P],
     "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
-    "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_softmax_rows_f16": [_P, _I, _I, _I, _P],
     "mofa_gn_nparts": [_I, _I],
     "mofa_gn_partial_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_gn_finalize": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "mofa_gn_reduce": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_gn_finalize_sums": [_P, _P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P],
     "mofa_affine_act_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_layernorm_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     "mofa_axpby_f16": [_P, _P, _I, _I, _I, _I, _F, _F, _P],

@@ -150,7 +150,10 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
 
 
 # ---- normalisation -------------------------------------------------------------------------------------
-def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None):
+def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None, reduce_fn=None,
+               frames_total=None):
+    """reduce_fn(sums fp64 [nstat,32,2]) -> all-reduced sums: used when the frames of a statistics set are sharded
+    over ranks (frames_total = number of frames of the set across all ranks)."""
     lib = L.load()
     _chk(x, F16)
     Cc = C_ if C_ is not None else x.shape[1]
@@ -161,8 +164,17 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
     shift = torch.empty((nframes, Cc), dtype=F32, device=x.device)
     st = L.stream_ptr()
     L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part), nframes, HW, Cc, _ld(x), st), "mofa_gn_partial_f16")
-    L.check(lib.mofa_gn_finalize(L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes, HW, Cc,
-                                 frames_per_stat, eps, st), "mofa_gn_finalize")
+    if reduce_fn is None:
+        L.check(lib.mofa_gn_finalize(L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes, HW,
+                                     Cc, frames_per_stat, eps, st), "mofa_gn_finalize")
+    else:
+        nstat = nframes // frames_per_stat
+        sums = torch.empty((nstat, 32, 2), dtype=torch.float64, device=x.device)
+        L.check(lib.mofa_gn_reduce(L.ptr(part), L.ptr(sums), nframes, HW, Cc, frames_per_stat, st), "mofa_gn_reduce")
+        sums = reduce_fn(sums)
+        cnt = float(frames_total) * HW * (Cc // 32)
+        L.check(lib.mofa_gn_finalize_sums(L.ptr(sums), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes,
+                                          Cc, frames_per_stat, cnt, eps, L.stream_ptr()), "mofa_gn_finalize_sums")
     if out is None:
         out = torch.empty((x.shape[0], Cc), dtype=F16, device=x.device)
     L.check(lib.mofa_affine_act_f16(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), nframes, HW, Cc, _ld(x), _ld(out),
@@ -200,14 +212,16 @@ def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None):
     return out
 
 
-def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=None):
+def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=None, Tq=None):
+    """k/v hold T frames per clip; q holds Tq <= T (Tq < T: frame-sharded clip with all-gathered K/V)."""
     lib = L.load()
-    assert _ld(q) == _ld(k) == _ld(v)
+    assert _ld(k) == _ld(v)
+    Tq = T if Tq is None else Tq
     scale = head_dim ** -0.5 if scale is None else scale
     if out is None:
-        out = torch.empty((nclips * T * HW, heads * head_dim), dtype=F16, device=q.device)
-    L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, T, HW, heads, head_dim, _ld(q),
-                                       _ld(out), scale, L.stream_ptr()), "mofa_attn_temporal_f16")
+        out = torch.empty((nclips * Tq * HW, heads * head_dim), dtype=F16, device=q.device)
+    L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, Tq, T, HW, heads, head_dim,
+                                       _ld(q), _ld(k), _ld(out), scale, L.stream_ptr()), "mofa_attn_temporal_f16")
     return out
 
 

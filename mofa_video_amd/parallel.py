@@ -1,0 +1,230 @@
+"""Clip partitioning across the GPUs of one MI355X node -- new work, the reference is single-GPU.
+
+Layout for N ranks (N in 1, 2, 4, 8, ...):  2-way CFG x (N/2)-way frames.
+    rank r:  half = r // frame_ranks  (0 = unconditional, 1 = conditional)   [N == 1: both halves on the one rank]
+             shard = r %  frame_ranks -> frames [f0, f1) of the clip (contiguous, sizes differ by at most 1)
+Weights are replicated.  Exchanges inside one denoise step (RCCL over xGMI through torch.distributed):
+    * temporal GroupNorm (statistics span all T frames): all-reduce of fp64 [32][2] partial sums   (frame group)
+    * temporal (3,1,1) convolution: one halo frame from each neighbour shard (batched p2p)        (frame group)
+    * temporal self-attention: all-gather of the K|V token columns along the frame axis            (frame group)
+    * CFG combine: the two halves of one frame shard swap their noise predictions                 (pair group)
+and once per clip: all-gather of the final latents before the VAE decode, whose chunks are independent and are
+dealt round-robin to ALL ranks.  Everything per-frame (2-D convs, spatial norms/attention, FFs, the adapter warps,
+zero convs, the Euler step) needs no communication.
+
+``Comm`` implementations: ``TorchComm`` (torch.distributed: "nccl" = RCCL on the GPUs, "gloo" in the CPU tests) and
+``ThreadComm`` (virtual ranks as threads of one process -- lets the whole sharded HIP path be checked against the
+unsharded one on a single GPU).
+"""
+import threading
+
+import torch
+
+
+def split_frames(T, n):
+    """contiguous shards, larger ones first: 25 over 4 -> [(0,7),(7,13),(13,19),(19,25)]"""
+    base, extra = divmod(T, n)
+    out, f = [], 0
+    for i in range(n):
+        k = base + (1 if i < extra else 0)
+        out.append((f, f + k))
+        f += k
+    return out
+
+
+class Layout:
+    def __init__(self, world, rank, T):
+        assert world >= 1 and (world == 1 or world % 2 == 0), "1 or an even number of ranks"
+        self.world, self.rank, self.T = world, rank, T
+        self.cfg_ranks = 2 if world >= 2 else 1
+        self.frame_ranks = world // self.cfg_ranks
+        assert self.frame_ranks <= T
+        self.half = rank // self.frame_ranks if self.cfg_ranks == 2 else None
+        self.shard = rank % self.frame_ranks
+        self.bounds = split_frames(T, self.frame_ranks)
+        self.f0, self.f1 = self.bounds[self.shard]
+        self.T_loc = self.f1 - self.f0
+        self.T_max = self.bounds[0][1] - self.bounds[0][0]
+        h = self.half or 0
+        self.frame_group = [h * self.frame_ranks + s for s in range(self.frame_ranks)]
+        self.pair_group = [self.shard, self.frame_ranks + self.shard] if self.cfg_ranks == 2 else [rank]
+        self.prev_rank = self.frame_group[self.shard - 1] if self.shard > 0 else None
+        self.next_rank = self.frame_group[self.shard + 1] if self.shard + 1 < self.frame_ranks else None
+        self.B_loc = 1 if self.cfg_ranks == 2 else 2
+
+    @property
+    def sharded_frames(self):
+        return self.frame_ranks > 1
+
+
+# ---------------------------------------------------------------------------------------------------------
+class TorchComm:
+    """torch.distributed backend (process group must be initialised).  Sub-groups are created once, by every rank,
+    in the same order (a torch.distributed requirement)."""
+
+    def __init__(self, layout_of_rank):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank = dist.get_rank()
+        world = dist.get_world_size()
+        self._groups = {}
+        seen = []
+        for r in range(world):
+            lay = layout_of_rank(r)
+            for g in (tuple(lay.frame_group), tuple(lay.pair_group)):
+                if g not in seen:
+                    seen.append(g)
+        for g in seen:
+            self._groups[g] = dist.new_group(list(g)) if len(g) > 1 else None
+        self._world_group = None
+
+    def _g(self, ranks):
+        return self._groups[tuple(ranks)]
+
+    def all_reduce_sum(self, t, ranks):
+        if len(ranks) > 1:
+            self.dist.all_reduce(t, group=self._g(ranks))
+        return t
+
+    def all_gather(self, t, ranks):
+        if len(ranks) == 1:
+            return [t]
+        outs = [torch.empty_like(t) for _ in ranks]
+        self.dist.all_gather(outs, t.contiguous(), group=self._g(ranks))
+        return outs
+
+    def all_gather_world(self, t):
+        n = self.dist.get_world_size()
+        if n == 1:
+            return [t]
+        outs = [torch.empty_like(t) for _ in range(n)]
+        self.dist.all_gather(outs, t.contiguous())
+        return outs
+
+    def exchange_halo(self, first, last, prev_rank, next_rank):
+        """send `first` to prev and `last` to next; receive prev's last and next's first (None at the clip ends)"""
+        dist = self.dist
+        ops, from_prev, from_next = [], None, None
+        if prev_rank is not None:
+            from_prev = torch.empty_like(last)
+            ops += [dist.P2POp(dist.isend, first.contiguous(), prev_rank), dist.P2POp(dist.irecv, from_prev, prev_rank)]
+        if next_rank is not None:
+            from_next = torch.empty_like(first)
+            ops += [dist.P2POp(dist.isend, last.contiguous(), next_rank), dist.P2POp(dist.irecv, from_next, next_rank)]
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        return from_prev, from_next
+
+
+class ThreadWorld:
+    """shared state of N virtual ranks living in N threads of one process"""
+
+    def __init__(self, world):
+        self.world = world
+        self.lock = threading.Lock()
+        self.barriers = {}
+        self.slots = {}
+
+    def _group_state(self, ranks):
+        key = tuple(ranks)
+        with self.lock:
+            if key not in self.barriers:
+                self.barriers[key] = threading.Barrier(len(key))
+                self.slots[key] = [None] * len(key)
+        return self.barriers[key], self.slots[key]
+
+
+class ThreadComm:
+    def __init__(self, tworld, rank):
+        self.tw, self.rank = tworld, rank
+
+    def _exchange(self, t, ranks):
+        bar, slots = self.tw._group_state(ranks)
+        slots[list(ranks).index(self.rank)] = t
+        bar.wait()
+        got = list(slots)
+        bar.wait()
+        return got
+
+    def all_reduce_sum(self, t, ranks):
+        if len(ranks) == 1:
+            return t
+        got = self._exchange(t.clone(), ranks)
+        acc = got[0].clone()
+        for g in got[1:]:
+            acc = acc + g          # fixed rank order on every rank -> identical result everywhere
+        t.copy_(acc)
+        return t
+
+    def all_gather(self, t, ranks):
+        if len(ranks) == 1:
+            return [t]
+        return [g.clone() for g in self._exchange(t.contiguous(), ranks)]
+
+    def all_gather_world(self, t):
+        return self.all_gather(t, list(range(self.tw.world)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+class FrameParallel:
+    """The per-rank object blocks consult (``Ctx.par``) when a clip's frames are sharded."""
+
+    def __init__(self, layout, comm, p2p=True):
+        self.lay, self.comm = layout, comm
+        self.T_full, self.T_loc, self.f0, self.f1 = layout.T, layout.T_loc, layout.f0, layout.f1
+        self.p2p = p2p and isinstance(comm, TorchComm)
+
+    # temporal GroupNorm -----------------------------------------------------------------------------------
+    def reduce_gn(self, sums):
+        return self.comm.all_reduce_sum(sums, self.lay.frame_group)
+
+    # temporal conv halo -----------------------------------------------------------------------------------
+    def halo(self, x, HW):
+        """x [T_loc*HW, C] -> [(T_loc+2)*HW, C]: neighbour shards' boundary frames before/after, zeros at clip ends
+        (= the conv's zero padding)."""
+        lay = self.lay
+        C = x.shape[1]
+        ext = torch.empty(((self.T_loc + 2) * HW, C), dtype=x.dtype, device=x.device)
+        ext[HW:(self.T_loc + 1) * HW].copy_(x)
+        first, last = x[:HW], x[(self.T_loc - 1) * HW:]
+        if self.p2p:
+            fp, fn = self.comm.exchange_halo(first, last, lay.prev_rank, lay.next_rank)
+        else:
+            both = torch.cat([first, last], 0)
+            got = self.comm.all_gather(both, lay.frame_group)
+            fp = got[lay.shard - 1][HW:] if lay.prev_rank is not None else None
+            fn = got[lay.shard + 1][:HW] if lay.next_rank is not None else None
+        if fp is not None:
+            ext[:HW].copy_(fp)
+        else:
+            ext[:HW].zero_()
+        if fn is not None:
+            ext[(self.T_loc + 1) * HW:].copy_(fn)
+        else:
+            ext[(self.T_loc + 1) * HW:].zero_()
+        return ext
+
+    # temporal attention K/V ---------------------------------------------------------------------------------
+    def gather_frames(self, t, rows_per_frame):
+        """t [T_loc*rows, C] (this shard's frames) -> [T_full*rows, C] in frame order (uneven shards are padded to
+        the largest for the collective and compacted afterwards)."""
+        lay = self.lay
+        C = t.shape[1]
+        pad_rows = lay.T_max * rows_per_frame
+        if t.shape[0] != pad_rows:
+            buf = torch.zeros((pad_rows, C), dtype=t.dtype, device=t.device)
+            buf[:t.shape[0]].copy_(t)
+        else:
+            buf = t.contiguous()
+        got = self.comm.all_gather(buf, lay.frame_group)
+        out = torch.empty((self.T_full * rows_per_frame, C), dtype=t.dtype, device=t.device)
+        for (a, b), g in zip(lay.bounds, got):
+            out[a * rows_per_frame:b * rows_per_frame].copy_(g[:(b - a) * rows_per_frame])
+        return out
+
+    # CFG pair ---------------------------------------------------------------------------------------------
+    def gather_cfg(self, noise):
+        """noise [T_loc*HW, 4] of this half -> [2*T_loc*HW, 4] (unconditional first)"""
+        got = self.comm.all_gather(noise, self.lay.pair_group)
+        return torch.cat(got, 0) if len(got) > 1 else got[0]

@@ -51,11 +51,14 @@ def _to_tensor_image(image, height, width, device):
 
 class FlowControlNetPipeline:
     def __init__(self, vae=None, image_encoder=None, unet=None, controlnet=None, scheduler=None,
-                 feature_extractor=None):
+                 feature_extractor=None, parallel=None):
+        """parallel: optional ``parallel.FrameParallel`` -- this process then computes one CFG half / one frame shard
+        of every clip (mofa_video_amd/parallel.py); all ranks must call the pipeline with identical inputs."""
         self.vae, self.image_encoder, self.unet, self.controlnet = vae, image_encoder, unet, controlnet
         self.scheduler, self.feature_extractor = scheduler, feature_extractor
         self.vae_scale_factor = 8
         self.device = unet.device
+        self.parallel = parallel
 
     def check_inputs(self, image, height, width):                      # pipeline.py:222-234
         if image is not None and not torch.is_tensor(image) and not isinstance(image, list):
@@ -110,7 +113,7 @@ class FlowControlNetPipeline:
             il = torch.cat([torch.zeros_like(il), il])
         il = il.contiguous()
 
-        # 4./5. schedule + latents
+        # 4./5. schedule + latents (every rank prepares the full clip's latents; it keeps its own frames below)
         sch.set_timesteps(num_inference_steps)
         timesteps = sch.timesteps
         lat = self.prepare_latents(1, T, unet.config.in_channels, height, width, generator, latents)
@@ -119,30 +122,58 @@ class FlowControlNetPipeline:
         # adapter condition: identical for both CFG halves (:393-397) -> computed once
         cond = _to_tensor_image(controlnet_condition, height, width, dev)
         flow = controlnet_flow.to(dev, torch.float32)
-        warped = cn.prepare_condition(cond[:1], flow[:1])
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)   # :430-440
 
-        c_cn, c_un = Ctx(2, T), Ctx(2, T)                                 # hold the per-clip invariant caches
-        x_in = torch.zeros((2 * T * h * w, max(unet.in_ld, cn.in_ld)), dtype=torch.float16, device=dev)
+        par = self.parallel
+        lay = par.lay if par is not None else None
+        if lay is not None:
+            assert lay.T == T, "Layout was built for a different frame count"
+        f0, f1 = (lay.f0, lay.f1) if lay is not None else (0, T)
+        Tl = f1 - f0                                                      # frames held by this rank
+        Bl = lay.B_loc if lay is not None else 2                          # CFG halves computed by this rank
+        half = lay.half if lay is not None else None
+        fpar = par if (lay is not None and lay.sharded_frames) else None
+        warped = cn.prepare_condition(cond[:1], flow[:1], frames=(f0, f1))
+        lat = lat[f0:f1].contiguous()
+        gspan = (max_guidance_scale - min_guidance_scale) / max(T - 1, 1)  # per-frame guidance is linear in the frame
+        g0, g1 = min_guidance_scale + gspan * f0, min_guidance_scale + gspan * (f1 - 1)
+
+        c_cn, c_un = Ctx(Bl, Tl), Ctx(Bl, Tl)                             # hold the per-clip invariant caches
+        rows = Tl * h * w
+        x_in = torch.zeros((2 * rows, max(unet.in_ld, cn.in_ld)), dtype=torch.float16, device=dev)
+        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
         self._num_timesteps = len(timesteps)
         for i, t in enumerate(timesteps):                                 # :447-511
             sigma, sigma_next = sch.sigma_pair(i)
             ops.prepare_model_input(lat, il, x_in, sigma)
-            cn.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_cn)
-            down_res, mid_res = cn.forward_tokens(x_in, c_cn, h, w, warped, controlnet_cond_scale)
-            unet.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_un)
-            noise = unet.forward_tokens(x_in, c_un, h, w, down_res, mid_res)
-            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
+            cn.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_cn, half=half, par=fpar)
+            down_res, mid_res = cn.forward_tokens(x_loc, c_cn, h, w, warped, controlnet_cond_scale)
+            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+            noise = unet.forward_tokens(x_loc, c_un, h, w, down_res, mid_res)
+            if Bl == 1:
+                noise = par.gather_cfg(noise)                             # both halves of this frame shard
+            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
             if callback_on_step_end is not None:
-                out = callback_on_step_end(self, i, t, {"latents": lat.reshape(1, T, 4, h, w)})
+                out = callback_on_step_end(self, i, t, {"latents": lat.reshape(1, Tl, 4, h, w)})
                 if out and "latents" in out:
-                    lat = out["latents"].to(dev, torch.float32).reshape(T, 4, h, w).contiguous()
+                    lat = out["latents"].to(dev, torch.float32).reshape(Tl, 4, h, w).contiguous()
 
+        if fpar is not None:                                              # reassemble the clip's latents on every rank
+            lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
         latents_out = lat.reshape(1, T, 4, h, w)
         if output_type == "latent":
             frames = latents_out
-        else:
+        elif lay is None or lay.world == 1:
             frames = decode_latents(self.vae, latents_out, T, decode_chunk_size)       # fp32 [1,3,T,H,W]
+        else:
+            # VAE chunks are independent (pipeline.py:204-213): dealt round-robin to all ranks; the result is the list
+            # of (first_frame, fp32 [n,3,H,W]) chunks this rank decoded
+            frames = []
+            sf = 1.0 / self.vae.config.scaling_factor
+            for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
+                if ci % lay.world == lay.rank:
+                    z = latents_out[0, s0:s0 + decode_chunk_size]
+                    frames.append((s0, self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)))
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)

@@ -66,14 +66,26 @@ class UNetSpatioTemporalConditionControlNetModel:
         return cls(module.state_dict(), getattr(module, "config", None), device)
 
     # ------------------------------------------------------------------------------------------------
-    def make_ctx(self, timestep, encoder_hidden_states, added_time_ids, B, T, base=None):
+    def make_ctx(self, timestep, encoder_hidden_states, added_time_ids, B, T, base=None, half=None, par=None):
+        """B, T = LOCAL batch / frame counts.  half: global CFG-half index when this rank computes one half only
+        (encoder_hidden_states / added_time_ids are then still the global 2-row tensors); par: FrameParallel."""
         c = base if base is not None else Ctx(B, T)
         ts = torch.as_tensor(timestep, dtype=torch.float32, device=self.device).reshape(-1)
         ts = ts.expand(B).contiguous() if ts.numel() == 1 else ts.contiguous()
-        c.temb_act = self.time(ts, added_time_ids.to(self.device, torch.float32).contiguous())
+        ids = added_time_ids.to(self.device, torch.float32)
+        if half is not None:
+            ids = ids[half:half + B]
+        c.temb_act = self.time(ts, ids.contiguous())
         if c.ctx16 is None:
-            e = encoder_hidden_states.to(self.device, torch.float32).reshape(B, -1).contiguous()
-            c.ctx16 = ops.cast_f32_to_f16(e)
+            e = encoder_hidden_states.to(self.device, torch.float32)
+            e = e.reshape(e.shape[0], -1).contiguous()
+            if half is not None:
+                c.ctx16_all = ops.cast_f32_to_f16(e)
+                c.ctx16 = c.ctx16_all[half:half + B].contiguous()
+                c.half = half
+            else:
+                c.ctx16 = ops.cast_f32_to_f16(e)
+        c.par = par
         return c
 
     def forward_tokens(self, x, c, H, W, down_res, mid_res):

@@ -1,0 +1,93 @@
+"""CPU tests (gloo, world_size 2 and 4, 127.0.0.1) of the clip-partitioning layer ``mofa_video_amd/parallel.py``:
+the layout arithmetic and every exchange primitive of the frame-sharded path, each checked against the
+single-process result computed with plain torch on the full clip."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+from mofa_video_amd.parallel import FrameParallel, Layout, TorchComm, split_frames
+
+
+def test_layout_arithmetic():
+    assert split_frames(25, 4) == [(0, 7), (7, 13), (13, 19), (19, 25)]
+    assert split_frames(25, 1) == [(0, 25)]
+    l = Layout(8, 5, 25)            # 2-way CFG x 4-way frames
+    assert (l.cfg_ranks, l.frame_ranks, l.half, l.shard) == (2, 4, 1, 1)
+    assert (l.f0, l.f1, l.T_loc, l.T_max) == (7, 13, 6, 7)
+    assert l.frame_group == [4, 5, 6, 7] and l.pair_group == [1, 5]
+    assert (l.prev_rank, l.next_rank) == (4, 6)
+    l = Layout(2, 1, 25)
+    assert (l.half, l.frame_group, l.pair_group, l.sharded_frames, l.B_loc) == (1, [1], [0, 1], False, 1)
+    l = Layout(1, 0, 25)
+    assert (l.half, l.B_loc, l.T_loc, l.pair_group) == (None, 2, 25, [0])
+    # every frame is owned exactly once per CFG half
+    for world in (2, 4, 8):
+        owned = {}
+        for r in range(world):
+            lay = Layout(world, r, 25)
+            for f in range(lay.f0, lay.f1):
+                owned.setdefault((lay.half, f), []).append(r)
+        assert len(owned) == 2 * 25 and all(len(v) == 1 for v in owned.values())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, T, HW, C):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lay = Layout(world, rank, T)
+        comm = TorchComm(lambda r: Layout(world, r, T))
+        par = FrameParallel(lay, comm)
+        g = torch.Generator().manual_seed(1234)              # identical "full clip" data on every rank
+        full = torch.randn(2, T * HW, C, generator=g)          # [half, frames*HW, C]
+        h = lay.half if lay.half is not None else 0
+        mine = full[h, lay.f0 * HW:lay.f1 * HW].contiguous()
+
+        # 1. halo exchange reproduces the zero-padded (3,1,1) convolution of the whole clip
+        w = torch.randn(C, C, 3, 1, 1, generator=g)
+        x5 = full[h].reshape(1, T, HW, C).permute(0, 3, 1, 2).unsqueeze(-1)          # [1,C,T,HW,1]
+        ref = F.conv3d(x5, w, padding=(1, 0, 0))[0, :, lay.f0:lay.f1, :, 0]             # [C, T_loc, HW]
+        ext = par.halo(mine, HW)
+        assert ext.shape[0] == (lay.T_loc + 2) * HW
+        e5 = ext.reshape(1, lay.T_loc + 2, HW, C).permute(0, 3, 1, 2).unsqueeze(-1)
+        got = F.conv3d(e5, w)[0, :, :, :, 0]                                             # valid conv over the halo'd shard
+        assert torch.allclose(got, ref, atol=1e-4), (rank, (got - ref).abs().max())
+
+        # 2. temporal GroupNorm statistics: all-reduced partial sums == sums over the whole clip
+        sums = torch.stack([mine.double().sum(0), (mine.double() ** 2).sum(0)], -1)[:32].reshape(1, -1, 2).clone()
+        red = par.reduce_gn(sums.clone())
+        fs = torch.stack([full[h].double().sum(0), (full[h].double() ** 2).sum(0)], -1)[:32].reshape(1, -1, 2)
+        assert torch.allclose(red, fs, rtol=1e-12)
+
+        # 3. K|V all-gather along the frame axis (uneven shards are padded and compacted)
+        kv = par.gather_frames(mine, HW)
+        assert torch.equal(kv, full[h])
+        lat = par.gather_frames(mine.reshape(lay.T_loc, HW * C), 1)
+        assert torch.equal(lat, full[h].reshape(T, HW * C))
+
+        # 4. CFG pair exchange: unconditional half first
+        if world >= 2:
+            both = par.gather_cfg(mine[:, :4].contiguous())
+            exp = torch.cat([full[0, lay.f0 * HW:lay.f1 * HW, :4], full[1, lay.f0 * HW:lay.f1 * HW, :4]], 0)
+            assert torch.equal(both, exp)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 5), (4, 5), (4, 7)])
+def test_frame_parallel_exchanges_gloo(world, T):
+    mp.spawn(_worker, args=(world, _free_port(), T, 6, 32), nprocs=world, join=True)
