@@ -29,6 +29,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T, H, W, STEPS, CHUNK = 25, 576, 1024, 25, 8
+if os.environ.get("MOFA_BENCH_DENOISE_STEPS"):   # functional checks only -- a line produced with this set is not a result
+    STEPS = int(os.environ["MOFA_BENCH_DENOISE_STEPS"])
 CLIP_TFLOP = 5638.0          # single-adapter clip, reference schedule (adapter work per step)
 MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
@@ -153,6 +155,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
+                    "single-GPU functional check of the multi-process path, see tests/README in DESIGN.md)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard",
                     help="N > 1: 'shard' = ONE clip per step partitioned over the ranks (2-way CFG x N/2 frame shards, "
                          "RCCL exchanges at the temporal ops; strong scaling) or 'replicas' = one independent clip per "
@@ -167,8 +171,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("MOFA_BENCH_ONE_GPU") == "1":      # functional check: all ranks share GPU 0 (gloo transport)
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -252,7 +261,7 @@ def main():
             "config": {"workload": "MOFA-Video-Traj, 25-frame 576x1024, 25 denoise steps + temporal VAE decode "
                                    "(chunk 8), single trajectory hint, SVD-XT UNet + MOFA-Adapter, CFG 1->3, "
                                    "seeded random weights in the reference checkpoint layout",
-                       "num_frames": T, "height": H, "width": W, "num_inference_steps": STEPS,
+                       "num_frames": T, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip (adapter prep + 25 denoise "
                        "steps + VAE decode)", "parallelism": par_desc,
                        "output_finite": finite,

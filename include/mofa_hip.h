@@ -48,8 +48,8 @@ int mofa_version(void);
  * models/unet_spatio_temporal_condition_controlnet.py:169-232, models/controlnet_sdv.py:259-309)
  * and the adapter's own convs (models/svdxt_featureflow_forward_controlnet_s2d_fixcmp_norefine.py:66-155).
  * ---------------------------------------------------------------------------------------- */
-enum { MOFA_MODE_PLAIN = 0, MOFA_MODE_CONV3X3 = 1, MOFA_MODE_CONVT3 = 2 };
-enum { MOFA_ACT_NONE = 0, MOFA_ACT_SILU = 1, MOFA_ACT_GEGLU_PAIR = 2 };
+enum { MOFA_MODE_PLAIN = 0, MOFA_MODE_CONV3X3 = 1, MOFA_MODE_CONVT3 = 2 };   /* CONV3X3 = k x k conv, k = ksize (3 or 7) */
+enum { MOFA_ACT_NONE = 0, MOFA_ACT_SILU = 1, MOFA_ACT_GEGLU_PAIR = 2, MOFA_ACT_RELU = 3 };
 
 typedef struct mofa_igemm_args {
     const void* x;      /* fp16 activations                                                  */
@@ -62,8 +62,9 @@ typedef struct mofa_igemm_args {
     int32_t M, N, Cin;  /* Cin % 64 == 0, N % 4 == 0                                         */
     int32_t ldx, ldo, ldr1, ldr2;
     int32_t mode;       /* MOFA_MODE_*                                                       */
-    /* MOFA_MODE_CONV3X3: rows are (img, oy, ox); pad 1; stride 1|2; up = 1|2 (nearest)      */
-    int32_t Hin, Win, Hout, Wout, stride, up;
+    /* MOFA_MODE_CONV3X3: rows are (img, oy, ox); k x k taps (ksize 3 or 7; 0 means 3), pad k/2; */
+    /* stride 1|2; up = 1|2 (nearest-neighbour upsampling of the input before the conv)      */
+    int32_t Hin, Win, Hout, Wout, stride, up, ksize;
     /* MOFA_MODE_CONVT3: rows are (frame, pixel); frames grouped in clips of T; T = 0: no     */
     /* clipping at clip ends (the caller placed halo frames before/after the rows)           */
     int32_t T, HW;
@@ -129,6 +130,19 @@ int mofa_layernorm_f16(const void* x, const float* gamma, const float* beta, voi
 /* ------------------------------------------------------------------------------------------
  * Element-wise / data movement
  * ---------------------------------------------------------------------------------------- */
+/* y = a*x + b*y on contiguous fp32 vectors (latent window accumulation / averaging of the Keypoint loop,
+ * MOFA-Video-Keypoint/pipeline/svdxt_pipeline_ctrlnet_loop.py:502-511) */
+int mofa_axpby_f32(const float* x, float* y, int64_t n, float a, float b, mofa_stream_t stream);
+/* nearest-neighbour resize of fp32 planes [n][H][W] -> [n][h][w], src = floor(dst * in/out) (F.interpolate 'nearest') */
+int mofa_resize_nearest_f32(const float* x, float* y, int n, int H, int W, int h, int w, mofa_stream_t stream);
+/* out[m][c] = a[m][c]*w[m % HW] + b[m][c]*(1 - w[m % HW]): Hybrid residual blend by the user mask
+ * (MOFA-Video-Hybrid/pipeline/pipeline.py:479-489); w fp32 [HW]; C % 8 == 0 */
+int mofa_mask_blend_f16(const void* a, const void* b, const float* w, void* out, int M, int C, int HW, int lda,
+                        int ldb, int ldo, mofa_stream_t stream);
+/* ForegroundMatting tail (MOFA-Video-Hybrid/models/occlusion/hourglass.py:266-280):
+ * mask = sigmoid(logit[m]); out[m][c] = warped[m][c]*mask + matting[m][c]*(1-mask); mask_out fp32 [M] (optional) */
+int mofa_matting_blend_f16(const void* warped, const void* matting, const void* logit, void* out, float* mask_out,
+                           int M, int C, int ldw, int ldm, int ldl, int ldo, mofa_stream_t stream);
 /* y[m][c] = a * x[m][c] + b * y[m][c]  (fp16 storage, fp32 math); C % 8 == 0 */
 int mofa_axpby_f16(const void* x, void* y, int M, int C, int ldx, int ldy, float a, float b, mofa_stream_t stream);
 /* out[m][j] = x[m][j] * gelu(x[m][Ch + j]), j < Ch  (diffusers GEGLU, erf gelu) */

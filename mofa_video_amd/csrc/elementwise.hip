@@ -249,4 +249,100 @@ extern "C" int mofa_cfg_euler_step(float* latents, const void* noise_pred, int T
     return MOFA_OK;
 }
 
-extern "C" int mofa_version(void) { return 100; }
+// ---- fp32 vector axpby (Keypoint window accumulation) -------------------------------------------------------------
+__global__ void axpby_f32_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a, float b) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = (b == 0.0f) ? a * x[i] : a * x[i] + b * y[i];
+}
+extern "C" int mofa_axpby_f32(const float* x, float* y, int64_t n, float a, float b, mofa_stream_t stream) {
+    if (!x || !y || n <= 0) return MOFA_EINVAL;
+    hipLaunchKernelGGL(axpby_f32_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n, a, b);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+__global__ void resize_nearest_kernel(const float* __restrict__ x, float* __restrict__ y, long long total, int H, int W,
+                                      int h, int w) {
+    const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % w);
+        const long long r = i / w;
+        const int oy = (int)(r % h);
+        const long long plane = r / h;
+        int iy = (int)floorf((float)oy * sy), ix = (int)floorf((float)ox * sx);
+        iy = iy < H - 1 ? iy : H - 1;
+        ix = ix < W - 1 ? ix : W - 1;
+        y[i] = x[(plane * H + iy) * W + ix];
+    }
+}
+extern "C" int mofa_resize_nearest_f32(const float* x, float* y, int n, int H, int W, int h, int w,
+                                       mofa_stream_t stream) {
+    if (!x || !y || n <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return MOFA_EINVAL;
+    const long long total = (long long)n * h * w;
+    hipLaunchKernelGGL(resize_nearest_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, y, total, H,
+                       W, h, w);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// ---- Hybrid residual blend: out = a*w + b*(1-w), w per pixel -----------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_blend_kernel(const f16* __restrict__ a, const f16* __restrict__ b,
+                                                         const float* __restrict__ w, f16* __restrict__ out,
+                                                         long long nvec, int CV, int HW, int lda, int ldb, int ldo) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long row = i / CV;
+        const int cv = (int)(i - row * CV);
+        const float m = w[row % HW];
+        const f16x8 av = *(const f16x8*)(a + (size_t)row * lda + cv * 8);
+        const f16x8 bv = *(const f16x8*)(b + (size_t)row * ldb + cv * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)av[e] * m + (float)bv[e] * (1.0f - m));
+        *(f16x8*)(out + (size_t)row * ldo + cv * 8) = o;
+    }
+}
+extern "C" int mofa_mask_blend_f16(const void* a, const void* b, const float* w, void* out, int M, int C, int HW, int lda,
+                                   int ldb, int ldo, mofa_stream_t stream) {
+    if (!a || !b || !w || !out || M <= 0 || C <= 0 || HW <= 0 || C % 8 != 0 || lda % 8 != 0 || ldb % 8 != 0 ||
+        ldo % 8 != 0)
+        return MOFA_EINVAL;
+    const long long nvec = (long long)M * (C / 8);
+    hipLaunchKernelGGL(mask_blend_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const f16*)a,
+                       (const f16*)b, w, (f16*)out, nvec, C / 8, HW, lda, ldb, ldo);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// ---- ForegroundMatting tail: out = warped*sigmoid(l) + matting*(1 - sigmoid(l)) --------------------------------------
+__global__ __launch_bounds__(256) void matting_blend_kernel(const f16* __restrict__ wp, const f16* __restrict__ mt,
+                                                            const f16* __restrict__ lg, f16* __restrict__ out,
+                                                            float* __restrict__ mask_out, long long nvec, int CV,
+                                                            int ldw, int ldm, int ldl, int ldo) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long row = i / CV;
+        const int cv = (int)(i - row * CV);
+        const float m = 1.0f / (1.0f + __expf(-(float)lg[(size_t)row * ldl]));
+        if (mask_out && cv == 0) mask_out[row] = m;
+        const f16x8 av = *(const f16x8*)(wp + (size_t)row * ldw + cv * 8);
+        const f16x8 bv = *(const f16x8*)(mt + (size_t)row * ldm + cv * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)((float)av[e] * m + (float)bv[e] * (1.0f - m));
+        *(f16x8*)(out + (size_t)row * ldo + cv * 8) = o;
+    }
+}
+extern "C" int mofa_matting_blend_f16(const void* warped, const void* matting, const void* logit, void* out,
+                                      float* mask_out, int M, int C, int ldw, int ldm, int ldl, int ldo,
+                                      mofa_stream_t stream) {
+    if (!warped || !matting || !logit || !out || M <= 0 || C <= 0 || C % 8 != 0 || ldw % 8 != 0 || ldm % 8 != 0 ||
+        ldo % 8 != 0 || ldl <= 0)
+        return MOFA_EINVAL;
+    const long long nvec = (long long)M * (C / 8);
+    hipLaunchKernelGGL(matting_blend_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (const f16*)warped, (const f16*)matting, (const f16*)logit, (f16*)out, mask_out, nvec, C / 8, ldw,
+                       ldm, ldl, ldo);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+extern "C" int mofa_version(void) { return 101; }

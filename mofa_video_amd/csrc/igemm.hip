@@ -52,9 +52,10 @@ __device__ __forceinline__ const f16* x_src(const mofa_igemm_args& a, const RowG
     if (a.mode == MOFA_MODE_PLAIN) {
         return x + (size_t)g.m * a.ldx;
     } else if (a.mode == MOFA_MODE_CONV3X3) {
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int vy = g.oy * a.stride + ky - 1;
-        const int vx = g.ox * a.stride + kx - 1;
+        const int ks = a.ksize > 0 ? a.ksize : 3;
+        const int ky = tap / ks, kx = tap - ky * ks;
+        const int vy = g.oy * a.stride + ky - (ks >> 1);
+        const int vx = g.ox * a.stride + kx - (ks >> 1);
         if (vy < 0 || vx < 0 || vy >= a.Hin * a.up || vx >= a.Win * a.up) return nullptr;
         const int iy = (a.up == 2) ? (vy >> 1) : vy;
         const int ix = (a.up == 2) ? (vx >> 1) : vx;
@@ -197,6 +198,9 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
                 if (a.act == MOFA_ACT_SILU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                } else if (a.act == MOFA_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
                 }
                 f16* po = out + (size_t)m * a.ldo + n;
                 if (full) {
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
     const int wm = wave / WN, wn = wave - wm * WN;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int taps = (a.mode == MOFA_MODE_CONV3X3) ? 9 : (a.mode == MOFA_MODE_CONVT3 ? 3 : 1);
+    const int taps = (a.mode == MOFA_MODE_CONV3X3) ? (a.ksize > 0 ? a.ksize * a.ksize : 9) : (a.mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const int kpt = a.Cin / BKS;         // K stages per tap
     const int nk = taps * kpt;
     const size_t Ktot = (size_t)taps * a.Cin;
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void igemm_regstage_kernel(const mofa_igemm
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int taps = (a.mode == MOFA_MODE_CONV3X3) ? 9 : (a.mode == MOFA_MODE_CONVT3 ? 3 : 1);
+    const int taps = (a.mode == MOFA_MODE_CONV3X3) ? (a.ksize > 0 ? a.ksize * a.ksize : 9) : (a.mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const int kpt = a.Cin / BK;
     const int nk = taps * kpt;
     const size_t Ktot = (size_t)taps * a.Cin;
@@ -448,6 +452,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (a->mode == MOFA_MODE_CONV3X3) {
         if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return MOFA_EINVAL;
         if ((a->stride != 1 && a->stride != 2) || (a->up != 1 && a->up != 2)) return MOFA_EINVAL;
+        if (a->ksize != 0 && a->ksize != 3 && a->ksize != 7) return MOFA_EINVAL;
         if (a->M % (a->Hout * a->Wout) != 0) return MOFA_EINVAL;
     }
     if (a->mode == MOFA_MODE_CONVT3 && (a->T < 0 || a->HW <= 0 || (a->T > 0 && a->M % (a->T * a->HW) != 0)))
@@ -496,7 +501,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
             // measured on MI355X (profiles/r01_igemm_config_sweep.md): 128-byte LDS rows (whole cache lines per DMA
             // row) beat the deeper 64-byte-row ring everywhere; 256x256 tiles win when N is wide relative to K
             // (GEGLU / QKV projections), 128x128 (2 workgroups per CU) otherwise.
-            const int taps = a->mode == MOFA_MODE_CONV3X3 ? 9 : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
+            const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
             const long long Ktot = (long long)taps * a->Cin;
             const int t256m = cdiv(a->M, 256), t256n = cdiv(a->N, 256);
             const bool big = (long long)t256n * 256 * 8 <= (long long)a->N * 9 && t256m * t256n >= 256 &&

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmofa_hip.so")
 
 MODE_PLAIN, MODE_CONV3X3, MODE_CONVT3 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GEGLU_PAIR = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU_PAIR, ACT_RELU = 0, 1, 2, 3
 
 
 class IgemmArgs(C.Structure):
@@ -25,7 +25,7 @@ class IgemmArgs(C.Structure):
         ("ldx", C.c_int32), ("ldo", C.c_int32), ("ldr1", C.c_int32), ("ldr2", C.c_int32),
         ("mode", C.c_int32),
         ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
-        ("stride", C.c_int32), ("up", C.c_int32),
+        ("stride", C.c_int32), ("up", C.c_int32), ("ksize", C.c_int32),
         ("T", C.c_int32), ("HW", C.c_int32),
         ("rv_div", C.c_int32), ("rv_mul", C.c_int32), ("rv_mod_in", C.c_int32), ("rv_mod_out", C.c_int32),
         ("act", C.c_int32),
@@ -50,6 +50,10 @@ PROTOTYPES = {
     "mofa_gn_finalize_sums": [_P, _P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P],
     "mofa_affine_act_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_layernorm_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
+    "mofa_axpby_f32": [_P, _P, _L, _F, _F, _P],
+    "mofa_resize_nearest_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "mofa_mask_blend_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mofa_matting_blend_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_axpby_f16": [_P, _P, _I, _I, _I, _I, _F, _F, _P],
     "mofa_geglu_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_copy2d_f16": [_P, _P, _I, _I, _I, _I, _P],

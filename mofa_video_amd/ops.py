@@ -74,21 +74,22 @@ def _chk(t, dtype):
 
 class ConvGeom:
     """Geometry of an implicit-GEMM launch."""
-    __slots__ = ("mode", "Hin", "Win", "Hout", "Wout", "stride", "up", "T", "HW")
+    __slots__ = ("mode", "Hin", "Win", "Hout", "Wout", "stride", "up", "T", "HW", "ksize")
 
-    def __init__(self, mode=L.MODE_PLAIN, Hin=0, Win=0, Hout=0, Wout=0, stride=1, up=1, T=0, HW=0):
+    def __init__(self, mode=L.MODE_PLAIN, Hin=0, Win=0, Hout=0, Wout=0, stride=1, up=1, T=0, HW=0, ksize=3):
         self.mode, self.Hin, self.Win, self.Hout, self.Wout = mode, Hin, Win, Hout, Wout
-        self.stride, self.up, self.T, self.HW = stride, up, T, HW
+        self.stride, self.up, self.T, self.HW, self.ksize = stride, up, T, HW, ksize
 
 
 PLAIN = ConvGeom()
 
 
-def conv3x3_geom(H, W, stride=1, up=1):
+def conv3x3_geom(H, W, stride=1, up=1, ksize=3):
+    """k x k convolution with padding k//2 (k = 3 or 7)"""
     Hv, Wv = H * up, W * up
     Ho = (Hv - 1) // stride + 1
     Wo = (Wv - 1) // stride + 1
-    return ConvGeom(L.MODE_CONV3X3, H, W, Ho, Wo, stride, up)
+    return ConvGeom(L.MODE_CONV3X3, H, W, Ho, Wo, stride, up, ksize=ksize)
 
 
 def convt3_geom(T, HW):
@@ -102,7 +103,7 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     _chk(x, F16); _chk(w, F16)
     N, Ktot = w.shape
     assert w.is_contiguous()
-    taps = {L.MODE_PLAIN: 1, L.MODE_CONV3X3: 9, L.MODE_CONVT3: 3}[geom.mode]
+    taps = {L.MODE_PLAIN: 1, L.MODE_CONV3X3: geom.ksize * geom.ksize, L.MODE_CONVT3: 3}[geom.mode]
     Cin = Ktot // taps
     assert Cin * taps == Ktot and x.shape[1] >= Cin, (x.shape, w.shape, taps)
     if M is None:
@@ -137,6 +138,7 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
         _chk(r2, F16); assert r2.shape[0] == M
     a.mode = geom.mode
     a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up = geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up
+    a.ksize = geom.ksize
     a.T, a.HW = geom.T, geom.HW
     a.rv_div, a.rv_mul, a.rv_mod_in, a.rv_mod_out = rv
     a.act = act
@@ -248,6 +250,48 @@ def axpby_(x, y, a=1.0, b=1.0):
     L.check(lib.mofa_axpby_f16(L.ptr(x), L.ptr(y), x.shape[0], x.shape[1], _ld(x), _ld(y), a, b, L.stream_ptr()),
             "mofa_axpby_f16")
     return y
+
+
+def axpby_f32_(x, y, a=1.0, b=1.0):
+    """y = a*x + b*y on contiguous fp32 tensors of equal size (in place on y)"""
+    lib = L.load()
+    _chk(x, F32); _chk(y, F32)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    L.check(lib.mofa_axpby_f32(L.ptr(x), L.ptr(y), x.numel(), a, b, L.stream_ptr()), "mofa_axpby_f32")
+    return y
+
+
+def resize_nearest_f32(x, h, w):
+    """fp32 [n,H,W] -> [n,h,w], F.interpolate(mode='nearest') index rule"""
+    lib = L.load()
+    _chk(x, F32)
+    n, H, W = x.shape
+    y = torch.empty((n, h, w), dtype=F32, device=x.device)
+    L.check(lib.mofa_resize_nearest_f32(L.ptr(x.contiguous()), L.ptr(y), n, H, W, h, w, L.stream_ptr()),
+            "mofa_resize_nearest_f32")
+    return y
+
+
+def mask_blend(a, b, w, HW, out=None):
+    """out = a*w[m % HW] + b*(1-w[m % HW])"""
+    lib = L.load()
+    assert a.shape == b.shape
+    if out is None:
+        out = torch.empty(a.shape, dtype=F16, device=a.device)
+    L.check(lib.mofa_mask_blend_f16(L.ptr(a), L.ptr(b), L.ptr(w), L.ptr(out), a.shape[0], a.shape[1], HW, _ld(a), _ld(b),
+                                    _ld(out), L.stream_ptr()), "mofa_mask_blend_f16")
+    return out
+
+
+def matting_blend(warped, matting, logit, want_mask=True):
+    lib = L.load()
+    M, Cc = warped.shape
+    out = torch.empty((M, Cc), dtype=F16, device=warped.device)
+    mask = torch.empty((M,), dtype=F32, device=warped.device) if want_mask else None
+    L.check(lib.mofa_matting_blend_f16(L.ptr(warped), L.ptr(matting), L.ptr(logit), L.ptr(out), L.ptr(mask), M, Cc,
+                                       _ld(warped), _ld(matting), _ld(logit), _ld(out), L.stream_ptr()),
+            "mofa_matting_blend_f16")
+    return out, mask
 
 
 def geglu(x, out=None):

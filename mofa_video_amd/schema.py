@@ -153,6 +153,41 @@ def controlnet_schema(config=None, conditioning_embedding_out_channels=(16, 32, 
     return d
 
 
+def _matting(d, p, c, num_blocks=3, block_expansion=64, max_features=512):
+    """ForegroundMatting (MOFA-Video-Hybrid/models/occlusion/hourglass.py:227-245): hourglass on 2c+2 channels"""
+    cin = 2 * c + 2
+    for i in range(num_blocks):
+        a = cin if i == 0 else min(max_features, block_expansion * (2 ** i))
+        b = min(max_features, block_expansion * (2 ** (i + 1)))
+        _conv(d, f"{p}.hourglass.encoder.down_blocks.{i}.conv", b, a, 3, 3)
+    for j, i in enumerate(range(num_blocks)[::-1]):
+        a = (1 if i == num_blocks - 1 else 2) * min(max_features, block_expansion * (2 ** (i + 1)))
+        b = min(max_features, block_expansion * (2 ** i))
+        _conv(d, f"{p}.hourglass.decoder.up_blocks.{j}.conv", b, a, 3, 3)
+    _conv(d, f"{p}.matting_mask", 1, block_expansion, 7, 7)
+    _conv(d, f"{p}.matting", c, block_expansion, 7, 7)
+
+
+def ldmk_controlnet_schema(config=None):
+    """landmark MOFA-Adapter (MOFA-Video-Hybrid/models/ldmk_ctrlnet.py:191-254): trajectory adapter without the
+    flow-encoder zero convs + landmark embedding + per-scale zero_outs / ForegroundMatting"""
+    cfg = dict(DEFAULT_CONFIG); cfg.update(config or {})
+    d = controlnet_schema(config)
+    for k in [k for k in d if k.startswith("flow_encoder.zeroconvs.")]:
+        del d[k]
+    boc = tuple(cfg["block_out_channels"])
+    ce = (16, 32, 64, 128)
+    _conv(d, "controlnet_ldmk_embedding.conv_in", ce[0], 3, 3, 3)
+    for i in range(len(ce) - 1):
+        _conv(d, f"controlnet_ldmk_embedding.blocks.{2 * i}", ce[i], ce[i], 3, 3)
+        _conv(d, f"controlnet_ldmk_embedding.blocks.{2 * i + 1}", ce[i + 1], ce[i], 3, 3)
+    _conv(d, "controlnet_ldmk_embedding.conv_out", boc[0], ce[-1], 3, 3)
+    for k, c in (("8", boc[0]), ("16", boc[0]), ("32", boc[1]), ("64", boc[2])):
+        _conv(d, f"zero_outs.{k}", c, c, 1, 1)
+        _matting(d, f"occlusions.{k}", c)
+    return d
+
+
 def vae_decoder_schema(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, out_channels=3):
     d = {}
     boc = tuple(block_out_channels)

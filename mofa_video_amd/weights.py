@@ -24,10 +24,10 @@ def pack_linear(w):
 
 
 def pack_conv3x3(w):
-    """nn.Conv2d weight [N, Cin, 3, 3] -> fp16 [N, 9*Cinpad], tap = ky*3 + kx major."""
+    """nn.Conv2d weight [N, Cin, k, k] (k = 3 or 7) -> fp16 [N, k*k*Cinpad], tap = ky*k + kx major."""
     w = _pad_cin(w, 1)
-    n, cin = w.shape[:2]
-    return w.permute(0, 2, 3, 1).reshape(n, 9 * cin).to(torch.float16).contiguous()
+    n, cin, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(n, kh * kw * cin).to(torch.float16).contiguous()
 
 
 def pack_conv3d_t3(w):

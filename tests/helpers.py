@@ -12,6 +12,18 @@ TINY_CN = dict(TINY, num_attention_heads=(1, 2, 2, 4))
 TINY_VAE = dict(block_out_channels=(64, 64, 128, 128))
 
 
+# reduced configs for the landmark adapter / Hybrid / Keypoint cases: level 0 keeps 320 channels because the reference
+# forward tests ``sample.shape[1] == 320`` literally (ldmk_ctrlnet.py:501); heads mirror (5,10,10,20) / (5,10,20,20)
+LDMK_CN = dict(block_out_channels=(320, 128, 256, 256), num_attention_heads=(5, 2, 2, 4), cross_attention_dim=128)
+LDMK_UNET = dict(block_out_channels=(320, 128, 256, 256), num_attention_heads=(5, 2, 4, 4), cross_attention_dim=128)
+
+
+def synthetic_landmarks(T, H, W, seed=44):
+    """pose images: sparse binary polylines-like pixels in [0,1], [1,T,3,H,W]"""
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(1, T, 3, H, W, generator=g) < 0.02).float()
+
+
 def rel_l2(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return ((a - b).norm() / (b.norm() + 1e-12)).item()

@@ -31,9 +31,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_igemm_args_struct_layout_matches_header():
     from mofa_video_amd.lib import IgemmArgs
-    # 7 pointers + 21 int32 + 3 float = 56 + 84 + 12 = 152 bytes, no padding surprises
-    assert ctypes.sizeof(IgemmArgs) == 152
-    assert IgemmArgs.M.offset == 56 and IgemmArgs.s_acc.offset == 140
+    # 7 pointers + 22 int32 + 3 float = 56 + 88 + 12 = 156 -> 160 with tail padding (8-byte aligned struct)
+    assert ctypes.sizeof(IgemmArgs) == 160
+    assert IgemmArgs.M.offset == 56 and IgemmArgs.ksize.offset == 112 and IgemmArgs.s_acc.offset == 144
 
 
 def test_argument_validation_without_gpu():
