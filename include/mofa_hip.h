@@ -143,6 +143,10 @@ int mofa_mask_blend_f16(const void* a, const void* b, const float* w, void* out,
  * mask = sigmoid(logit[m]); out[m][c] = warped[m][c]*mask + matting[m][c]*(1-mask); mask_out fp32 [M] (optional) */
 int mofa_matting_blend_f16(const void* warped, const void* matting, const void* logit, void* out, float* mask_out,
                            int M, int C, int ldw, int ldm, int ldl, int ldo, mofa_stream_t stream);
+/* F.interpolate(scale_factor=1/s, nearest) of token-major maps [n][H][W][C] -> [n][H/s][W/s][C]
+ * (landmark embedding pyramid, MOFA-Video-Hybrid/models/ldmk_ctrlnet.py:399-403) */
+int mofa_subsample_tokens_f16(const void* x, void* y, int n, int H, int W, int s, int C, int ldx, int ldy,
+                              mofa_stream_t stream);
 /* y[m][c] = a * x[m][c] + b * y[m][c]  (fp16 storage, fp32 math); C % 8 == 0 */
 int mofa_axpby_f16(const void* x, void* y, int M, int C, int ldx, int ldy, float a, float b, mofa_stream_t stream);
 /* out[m][j] = x[m][j] * gelu(x[m][Ch + j]), j < Ch  (diffusers GEGLU, erf gelu) */

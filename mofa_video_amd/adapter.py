@@ -150,11 +150,18 @@ class FlowControlNet:
             ops.axpby_(warped, sample[b * rows:(b + 1) * rows], 1.0, 1.0)
 
     def forward_tokens(self, x, c, H, W, warped, conditioning_scale=1.0):
-        """-> (12 residual token tensors, mid residual), already multiplied by conditioning_scale."""
+        """warped: the list from ``prepare_condition`` (or an ``AdapterCondition`` carrying .warped and, for the
+        landmark adapter, .ldmk = {h*w: landmark embedding tokens}).
+        -> (12 residual token tensors, mid residual), already multiplied by conditioning_scale."""
         B = c.B
         cs = float(conditioning_scale)
+        ldmk = getattr(warped, "ldmk", None)
+        warped = getattr(warped, "warped", warped)
+        c0 = self.config.block_out_channels[0]
         sample = self.conv_in(x, H, W)
         self._add_warped(sample, warped[0], B)                               # :328
+        if ldmk is not None:
+            self._add_warped(sample, ldmk[H * W], B)                         # ldmk_ctrlnet.py:474
         zi = 0
         outs = [self.controlnet_down_blocks[zi](sample, s_acc=cs)]           # zero conv applied eagerly so the
         zi += 1                                                              # later in-place adds are safe
@@ -165,6 +172,8 @@ class FlowControlNet:
                 outs.append(self.controlnet_down_blocks[zi](r, s_acc=cs))
                 zi += 1
             self._add_warped(sample, warped[min(count, length - 1)], B)      # :349
+            if ldmk is not None and sample.shape[1] == c0:                   # ldmk_ctrlnet.py:501-504 (== 320)
+                self._add_warped(sample, ldmk[H * W], B)
             count += 1
         self._add_warped(sample, warped[-1], B)                              # :354
         sample = self.mid_block(sample, c, H, W)
@@ -197,5 +206,143 @@ class FlowControlNet:
             return (res, midn, controlnet_flow, None)
         return _Config(down_block_res_samples=res, mid_block_res_sample=midn, controlnet_flow=controlnet_flow,
                        cmp_output=None)
+
+    __call__ = forward
+
+
+
+# =========================================================================================================
+# landmark MOFA-Adapter (Hybrid / Keypoint trees)
+# =========================================================================================================
+class AdapterCondition:
+    """timestep-invariant adapter state of one clip (or one window): warped first-frame pyramids, landmark embedding
+    pyramid, occlusion masks"""
+
+    def __init__(self, warped, ldmk=None, occlusion_masks=None):
+        self.warped, self.ldmk, self.occlusion_masks = warped, ldmk, occlusion_masks
+
+
+class _Matting:
+    """ForegroundMatting (MOFA-Video-Hybrid/models/occlusion/hourglass.py:227-280) over all flow frames at once."""
+
+    def __init__(self, s, C):
+        self.C = C
+        hg = s.sub("hourglass")
+        self.enc = [Conv3x3(hg.sub(f"encoder.down_blocks.{i}.conv")) for i in range(3)]
+        self.dec = [Conv3x3(hg.sub(f"decoder.up_blocks.{i}.conv")) for i in range(3)]
+        self.head_mask = Conv3x3(s.sub("matting_mask"), pad_n=True)         # 7x7, 64 -> 1 (padded to 4 rows)
+        self.head_mat = Conv3x3(s.sub("matting"))                           # 7x7, 64 -> C
+        self.in_ld = self.enc[0].w.shape[1] // 9                            # 2C+2 padded to a multiple of 64
+
+    def __call__(self, ref, flow, warped, nf, h, w):
+        """ref fp16 [h*w, C]; flow fp32 [nf,2,h,w]; warped fp16 [nf*h*w, C] -> (blended [nf*h*w, C], mask fp32 [nf*h*w])"""
+        C, hw = self.C, h * w
+        x = torch.zeros((nf * hw, self.in_ld), dtype=torch.float16, device=ref.device)
+        for i in range(nf):
+            ops.copy2d(ref, x[i * hw:(i + 1) * hw, :C])
+        ops.nchw_to_tokens(flow, out=x[:, C:C + 2])
+        self._copy_unaligned(warped, x, C)     # column C+2 is only 4-byte aligned: scalar-store path
+        relu = dict(act=L.ACT_RELU)
+        e1 = self.enc[0](x, h, w, **relu)
+        e2 = self.enc[1](e1, h, w, **relu)
+        e3 = self.enc[2](e2, h, w, **relu)
+        d = self.dec[0](e3, h, w, **relu)
+        d = self.dec[1](ops.concat_channels(e2, d), h, w, **relu)
+        d = self.dec[2](ops.concat_channels(e1, d), h, w, **relu)
+        g7 = ops.conv3x3_geom(h, w, ksize=7)
+        logit = ops.igemm(d, self.head_mask.w, self.head_mask.b, geom=g7)    # [nf*hw, 4], column 0 = logit
+        mat = ops.igemm(d, self.head_mat.w, self.head_mat.b, geom=g7)
+        return ops.matting_blend(warped, mat, logit)
+
+    @staticmethod
+    def _copy_unaligned(warped, x, C):
+        # the warped block starts at column C+2 (4-byte aligned only): go through an fp32 NCHW view of the tokens
+        n = warped.shape[0]
+        t = ops.tokens_to_nchw(warped, 1, warped.shape[1], n, 1)            # [1, C, n, 1] fp32
+        ops.nchw_to_tokens(t, out=x[:, C + 2:2 * C + 2])
+
+
+class LandmarkFlowControlNet(FlowControlNet):
+    """``FlowControlNet`` of MOFA-Video-Hybrid/models/ldmk_ctrlnet.py (= MOFA-Video-Keypoint/models/ldmk_ctrlnet.py):
+    the trajectory adapter (first-frame encoder without zero convs) + landmark-image embedding added at the 320-channel
+    stages + per-scale ForegroundMatting and zero-out on every warped frame.  ``forward`` adds the ``landmarks``
+    argument and returns the occlusion masks 4th (:322-339, :569-570)."""
+
+    def __init__(self, state_dict, config=None, device="cuda", dtype=torch.float16):
+        super().__init__(state_dict, config, device, dtype)
+        s = Sub(state_dict, "", device)
+        boc = tuple(self.config.block_out_channels)
+        self.ldmk_embedding = _CondEmbedding(s.sub("controlnet_ldmk_embedding"))
+        ch = {"8": boc[0], "16": boc[0], "32": boc[1], "64": boc[2]}
+        self.zero_outs = {k: Linear(s.sub(f"zero_outs.{k}")) for k in ch}
+        self.occlusions = {k: _Matting(s.sub(f"occlusions.{k}"), c) for k, c in ch.items()}
+
+    def prepare_condition(self, controlnet_cond, controlnet_flow, landmarks=None, frames=None):
+        """landmarks [1,T,3,H,W] (pose images).  -> AdapterCondition for frames [f0, f1)."""
+        cond = controlnet_cond.to(self.device, torch.float32)
+        flow = controlnet_flow.to(self.device, torch.float32)
+        assert cond.shape[0] == 1 and flow.shape[0] == 1
+        _, _, H, W = cond.shape
+        T = flow.shape[1] + 1
+        f0, f1 = frames if frames is not None else (0, T)
+        x = ops.nchw_to_tokens(cond, ld=self.cond_embedding.in_ld)
+        f, h, w = self.cond_embedding(x, H, W)
+        feats = [(f, h, w)]
+        e = f
+        for enc in self.flow_encoders:                                       # no zero convs (ldmk_ctrlnet.py:152-161)
+            e = enc(e, h, w, act=L.ACT_SILU)
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            feats.append((e, h, w))
+        w0 = max(f0, 1)
+        fl = flow[0, w0 - 1:f1 - 1].contiguous() if f1 > w0 else None
+        warped, masks = [], []
+        for (ft, h, w) in feats:
+            s = H // h
+            hw = h * w
+            allf = torch.empty(((f1 - f0) * hw, ft.shape[1]), dtype=torch.float16, device=self.device)
+            off = 0
+            if f0 == 0:
+                ops.copy2d(ft, allf[:hw])
+                off = hw
+            if fl is not None:
+                nf = fl.shape[0]
+                fs = ops.flow_downscale(fl, s)
+                wr = ops.softsplat_avg_tokens(ft, fs, h, w)                  # :301
+                wr, m = self.occlusions[str(s)](ft, fs, wr, nf, h, w)        # :310-312
+                self.zero_outs[str(s)](wr, out=allf[off:])                   # :316
+                masks.append(m.reshape(nf, 1, h, w))
+            warped.append(allf)
+        ldmk = None
+        if landmarks is not None:
+            lm = landmarks.to(self.device, torch.float32)[0, f0:f1].contiguous()      # [Tl,3,H,W]
+            Tl = lm.shape[0]
+            xl = ops.nchw_to_tokens(lm, ld=self.ldmk_embedding.in_ld)
+            l0, lh, lw = self.ldmk_embedding(xl, H, W)                       # [Tl*h*w, 320]
+            ldmk = {lh * lw: l0}
+            half = ops.subsample_tokens(l0, Tl, lh, lw, 2)                   # F.interpolate(scale_factor=1/2), :399-403
+            ldmk[(lh // 2) * (lw // 2)] = half
+        return AdapterCondition(warped, ldmk, masks)
+
+    def forward(self, sample, timestep, encoder_hidden_states, added_time_ids, controlnet_cond=None,
+                controlnet_flow=None, landmarks=None, image_only_indicator=None, return_dict=True, guess_mode=False,
+                conditioning_scale=1.0):
+        B, T, Cin, H, W = sample.shape
+        c = self.make_ctx(timestep, encoder_hidden_states, added_time_ids, B, T)
+        cond = self.prepare_condition(controlnet_cond[:1], controlnet_flow[:1], landmarks[:1])
+        x = ops.nchw_to_tokens(sample.reshape(B * T, Cin, H, W).to(self.device, torch.float32), ld=self.in_ld)
+        outs, mid = self.forward_tokens(x, c, H, W, cond, conditioning_scale)
+        dims, h, w = [(H, W)], H, W
+        for blk in self.down_blocks:
+            dims += [(h, w)] * len(blk.resnets)
+            if blk.down is not None:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+                dims.append((h, w))
+        res = [ops.tokens_to_nchw(o, B * T, o.shape[1], hh, ww).to(sample.dtype) for o, (hh, ww) in zip(outs, dims)]
+        midn = ops.tokens_to_nchw(mid, B * T, mid.shape[1], h, w).to(sample.dtype)
+        occ = [m.unsqueeze(0).expand(B, -1, -1, -1, -1) for m in cond.occlusion_masks]
+        if not return_dict:
+            return (res, midn, controlnet_flow, occ)
+        return _Config(down_block_res_samples=res, mid_block_res_sample=midn, controlnet_flow=controlnet_flow,
+                       occlusion_masks=occ)
 
     __call__ = forward

@@ -345,4 +345,31 @@ extern "C" int mofa_matting_blend_f16(const void* warped, const void* matting, c
     return MOFA_OK;
 }
 
-extern "C" int mofa_version(void) { return 101; }
+// ---- F.interpolate(x, scale_factor=1/s) (nearest) on token-major maps: out[(n, y, x)] = in[(n, y*s, x*s)] --------------
+__global__ __launch_bounds__(256) void subsample_tokens_kernel(const f16* __restrict__ x, f16* __restrict__ y,
+                                                               long long nvec, int CV, int H, int W, int s, int ldx,
+                                                               int ldy) {
+    const int h = H / s, w = W / s;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long row = i / CV;
+        const int cv = (int)(i - row * CV);
+        const int ox = (int)(row % w);
+        const long long r = row / w;
+        const int oy = (int)(r % h);
+        const long long n = r / h;
+        const long long src = (n * H + (long long)oy * s) * W + (long long)ox * s;
+        *(f16x8*)(y + (size_t)row * ldy + cv * 8) = *(const f16x8*)(x + (size_t)src * ldx + cv * 8);
+    }
+}
+extern "C" int mofa_subsample_tokens_f16(const void* x, void* y, int n, int H, int W, int s, int C, int ldx, int ldy,
+                                         mofa_stream_t stream) {
+    if (!x || !y || n <= 0 || s <= 0 || H % s != 0 || W % s != 0 || C % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0)
+        return MOFA_EINVAL;
+    const long long nvec = (long long)n * (H / s) * (W / s) * (C / 8);
+    hipLaunchKernelGGL(subsample_tokens_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
+                       (f16*)y, nvec, C / 8, H, W, s, ldx, ldy);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+extern "C" int mofa_version(void) { return 102; }

@@ -54,6 +54,7 @@ PROTOTYPES = {
     "mofa_resize_nearest_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "mofa_mask_blend_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_matting_blend_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "mofa_subsample_tokens_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mofa_axpby_f16": [_P, _P, _I, _I, _I, _I, _F, _F, _P],
     "mofa_geglu_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_copy2d_f16": [_P, _P, _I, _I, _I, _I, _P],

@@ -343,11 +343,28 @@ def cast_f16_to_f32(x):
     return y
 
 
-def nchw_to_tokens(x, ld=None, scale=1.0):
-    """fp32 [n,C,H,W] -> fp16 token-major [n*H*W, ld] (zero-padded channels when ld > C)."""
+def subsample_tokens(x, n, H, W, s):
+    """token-major [n*H*W, C] -> [n*(H/s)*(W/s), C], nearest (F.interpolate(scale_factor=1/s))"""
+    lib = L.load()
+    _chk(x, F16)
+    Cc = x.shape[1]
+    y = torch.empty((n * (H // s) * (W // s), Cc), dtype=F16, device=x.device)
+    L.check(lib.mofa_subsample_tokens_f16(L.ptr(x), L.ptr(y), n, H, W, s, Cc, _ld(x), _ld(y), L.stream_ptr()),
+            "mofa_subsample_tokens_f16")
+    return y
+
+
+def nchw_to_tokens(x, ld=None, scale=1.0, out=None):
+    """fp32 [n,C,H,W] -> fp16 token-major [n*H*W, ld] (zero-padded channels when ld > C).  out: an existing
+    token-major view (e.g. a column block of a wider buffer) to write the C channels into."""
     lib = L.load()
     _chk(x, F32)
     n, Cc, H, W = x.shape
+    if out is not None:
+        assert out.shape[0] == n * H * W and out.shape[1] >= Cc
+        L.check(lib.mofa_nchw_f32_to_nhwc_f16(L.ptr(x.contiguous()), L.ptr(out), n, Cc, H * W, _ld(out), float(scale),
+                                              L.stream_ptr()), "mofa_nchw_f32_to_nhwc_f16")
+        return out
     ld = ld or Cc
     y = (torch.zeros if ld > Cc else torch.empty)((n * H * W, ld), dtype=F16, device=x.device)
     L.check(lib.mofa_nchw_f32_to_nhwc_f16(L.ptr(x.contiguous()), L.ptr(y), n, Cc, H * W, ld, float(scale), L.stream_ptr()),

@@ -74,6 +74,24 @@ class FlowControlNetPipeline:
                                   device=generator.device if generator is not None else "cpu")
         return latents.to(self.device, torch.float32) * self.scheduler.init_noise_sigma   # :272
 
+    def _conditioning(self, image, image_embeddings, image_latents):
+        dev = self.device
+        if image_embeddings is None:
+            if self.image_encoder is None:
+                raise ValueError("pass image_embeddings=... (CLIP runs outside the hot path)")
+            image_embeddings = self.image_encoder(image)
+        if image_latents is None:
+            if self.vae is None or not hasattr(self.vae, "encode"):
+                raise ValueError("pass image_latents=... (VAE encode runs outside the hot path)")
+            image_latents = self.vae.encode(image)
+        emb = image_embeddings.to(dev, torch.float32).reshape(-1, 1, image_embeddings.shape[-1])
+        if emb.shape[0] == 1:                                             # :133-139 uncond = zeros
+            emb = torch.cat([torch.zeros_like(emb), emb])
+        il = image_latents.to(dev, torch.float32)
+        if il.shape[0] == 1:                                              # :153-159
+            il = torch.cat([torch.zeros_like(il), il])
+        return emb, il.contiguous()
+
     # ---------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, image=None, controlnet_condition=None, controlnet_flow=None, height: int = 576,
@@ -97,21 +115,7 @@ class FlowControlNetPipeline:
         T = num_frames
 
         # 3./4. image conditioning (computed before the hot path)
-        if image_embeddings is None:
-            if self.image_encoder is None:
-                raise ValueError("pass image_embeddings=... (CLIP runs outside the hot path)")
-            image_embeddings = self.image_encoder(image)
-        if image_latents is None:
-            if self.vae is None or not hasattr(self.vae, "encode"):
-                raise ValueError("pass image_latents=... (VAE encode runs outside the hot path)")
-            image_latents = self.vae.encode(image)
-        emb = image_embeddings.to(dev, torch.float32).reshape(-1, 1, image_embeddings.shape[-1])
-        if emb.shape[0] == 1:                                             # :133-139 uncond = zeros
-            emb = torch.cat([torch.zeros_like(emb), emb])
-        il = image_latents.to(dev, torch.float32)
-        if il.shape[0] == 1:                                              # :153-159
-            il = torch.cat([torch.zeros_like(il), il])
-        il = il.contiguous()
+        emb, il = self._conditioning(image, image_embeddings, image_latents)
 
         # 4./5. schedule + latents (every rank prepares the full clip's latents; it keeps its own frames below)
         sch.set_timesteps(num_inference_steps)
@@ -174,6 +178,157 @@ class FlowControlNetPipeline:
                 if ci % lay.world == lay.rank:
                     z = latents_out[0, s0:s0 + decode_chunk_size]
                     frames.append((s0, self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)))
+        if not return_dict:
+            return frames, controlnet_flow
+        return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
+
+
+
+# =========================================================================================================
+# Hybrid: face (landmark) adapter + drag (trajectory) adapter, residuals blended by the user mask
+# (MOFA-Video-Hybrid/pipeline/pipeline.py:293-320 signature, :443-507 loop, :479-489 blend)
+# =========================================================================================================
+class HybridFlowControlNetPipeline(FlowControlNetPipeline):
+    def __init__(self, vae=None, image_encoder=None, unet=None, face_controlnet=None, drag_controlnet=None,
+                 scheduler=None, feature_extractor=None):
+        super().__init__(vae, image_encoder, unet, face_controlnet, scheduler, feature_extractor)
+        self.face_controlnet, self.drag_controlnet = face_controlnet, drag_controlnet
+
+    @torch.no_grad()
+    def __call__(self, image=None, controlnet_condition=None, controlnet_flow=None, landmarks=None, drag_flow=None,
+                 mask=None, height: int = 576, width: int = 1024, num_frames: Optional[int] = None,
+                 num_inference_steps: int = 25, min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0,
+                 fps: int = 7, motion_bucket_id: int = 127, noise_aug_strength: float = 0.02,
+                 decode_chunk_size: Optional[int] = None, num_videos_per_prompt: Optional[int] = 1, generator=None,
+                 latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pt",
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+                 return_dict: bool = True, ctrl_scale_traj=1.0, ctrl_scale_ldmk=1.0, batch_size=1, *,
+                 image_embeddings=None, image_latents=None):
+        unet, face, drag, sch, dev = self.unet, self.face_controlnet, self.drag_controlnet, self.scheduler, self.device
+        T = num_frames if num_frames is not None else unet.config.num_frames
+        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else T
+        self.check_inputs(image, height, width)
+        h, w = height // 8, width // 8
+        emb, il = self._conditioning(image, image_embeddings, image_latents)
+        sch.set_timesteps(num_inference_steps)
+        timesteps = sch.timesteps
+        lat = self.prepare_latents(1, T, unet.config.in_channels, height, width, generator, latents).reshape(T, 4, h, w).contiguous()
+        cond = _to_tensor_image(controlnet_condition, height, width, dev)
+        cf = face.prepare_condition(cond[:1], controlnet_flow.to(dev, torch.float32)[:1], landmarks[:1])
+        cd = drag.prepare_condition(cond[:1], drag_flow.to(dev, torch.float32)[:1])
+        # user mask, nearest-resized to every residual resolution (:481, :488) -- timestep-invariant
+        m = mask.to(dev, torch.float32).reshape(1, height, width)
+        masks = {}
+        hh, ww = h, w
+        for _ in range(4):
+            masks[hh * ww] = ops.resize_nearest_f32(m, hh, ww).reshape(-1).contiguous()
+            hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
+        c_f, c_d, c_u = Ctx(2, T), Ctx(2, T), Ctx(2, T)
+        x_in = torch.zeros((2 * T * h * w, unet.in_ld), dtype=torch.float16, device=dev)
+        for i, t in enumerate(timesteps):
+            sigma, sigma_next = sch.sigma_pair(i)
+            ops.prepare_model_input(lat, il, x_in, sigma)
+            face.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_f)
+            df, mf = face.forward_tokens(x_in, c_f, h, w, cf, ctrl_scale_ldmk)
+            drag.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_d)
+            dd, md = drag.forward_tokens(x_in, c_d, h, w, cd, ctrl_scale_traj)
+            down = []
+            for a, b in zip(df, dd):
+                hw = a.shape[0] // (2 * T)
+                down.append(ops.mask_blend(a, b, masks[hw], hw))
+            hw = mf.shape[0] // (2 * T)
+            mid = ops.mask_blend(mf, md, masks[hw], hw)
+            unet.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_u)
+            noise = unet.forward_tokens(x_in, c_u, h, w, down, mid)
+            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
+        latents_out = lat.reshape(1, T, 4, h, w)
+        frames = latents_out if output_type == "latent" else decode_latents(self.vae, latents_out, T, decode_chunk_size)
+        if not return_dict:
+            return frames, controlnet_flow
+        return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
+
+
+# =========================================================================================================
+# Keypoint long video ("periodic sampling"): overlapping temporal windows with frame 0 prepended, one Euler step per
+# window, overlap average (MOFA-Video-Keypoint/pipeline/svdxt_pipeline_ctrlnet_loop.py:289-294 signature,
+# :426-429 views, :445-511 loop)
+# =========================================================================================================
+def window_views(num_frames, window_size, stride):
+    window_num = (num_frames - window_size) // stride + 1
+    views = [(1 + i * stride, i * stride + window_size) for i in range(window_num)]
+    return views + [(num_frames - window_size + 1, num_frames)]
+
+
+class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
+    @torch.no_grad()
+    def __call__(self, image=None, controlnet_condition=None, controlnet_flow=None, landmarks=None, window_size: int = 25,
+                 stride: int = 12, height: int = 576, width: int = 1024, num_frames: Optional[int] = None,
+                 num_inference_steps: int = 25, min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0,
+                 fps: int = 7, motion_bucket_id: int = 127, noise_aug_strength: float = 0.02,
+                 decode_chunk_size: Optional[int] = None, num_videos_per_prompt: Optional[int] = 1, generator=None,
+                 latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pt",
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs: List[str] = ["latents"],
+                 return_dict: bool = True, controlnet_cond_scale=1.0, batch_size=1, *, image_embeddings=None,
+                 image_latents=None):
+        unet, cn, sch, dev = self.unet, self.controlnet, self.scheduler, self.device
+        N = num_frames if num_frames is not None else unet.config.num_frames
+        Tw = window_size
+        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else N
+        self.check_inputs(image, height, width)
+        h, w = height // 8, width // 8
+        emb, il = self._conditioning(image, image_embeddings, image_latents)
+        sch.set_timesteps(num_inference_steps)
+        timesteps = sch.timesteps
+        lat = self.prepare_latents(1, N, unet.config.in_channels, height, width, generator, latents).reshape(N, 4, h, w).contiguous()
+        cond = _to_tensor_image(controlnet_condition, height, width, dev)
+        flow = controlnet_flow.to(dev, torch.float32)
+        views = window_views(N, Tw, stride)
+        # adapter state per DISTINCT window is timestep-invariant: computed once per clip (the reference recomputes it
+        # every step; its last view often repeats the previous one -- SURVEY 3.5 -- and is computed once here)
+        conds = {}
+        for (t0, t1) in views:
+            if (t0, t1) not in conds:
+                lm = torch.cat([landmarks[:, 0:1], landmarks[:, t0:t1]], dim=1)
+                conds[(t0, t1)] = cn.prepare_condition(cond[:1], flow[:1, t0 - 1:t1 - 1], lm)
+        added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
+        ctxs = {v: (Ctx(2, Tw), Ctx(2, Tw)) for v in conds}
+        x_in = torch.zeros((2 * Tw * h * w, unet.in_ld), dtype=torch.float16, device=dev)
+        value = torch.empty_like(lat)
+        fsz = 4 * h * w
+        for i, t in enumerate(timesteps):
+            sigma, sigma_next = sch.sigma_pair(i)
+            count = [0] * N
+            touched = [False] * N
+            done = {}
+            for idx, (t0, t1) in enumerate(views):
+                if (t0, t1) not in done:
+                    lw = torch.cat([lat[0:1], lat[t0:t1]], dim=0).contiguous()            # frame 0 + window frames
+                    ops.prepare_model_input(lw, il, x_in, sigma)
+                    c_cn, c_un = ctxs[(t0, t1)]
+                    cn.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_cn)
+                    down, mid = cn.forward_tokens(x_in, c_cn, h, w, conds[(t0, t1)], controlnet_cond_scale)
+                    unet.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_un)
+                    noise = unet.forward_tokens(x_in, c_un, h, w, down, mid)
+                    ops.cfg_euler_step_(lw, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
+                    done[(t0, t1)] = lw
+                lw = done[(t0, t1)]
+                # value[0:t1] += lw (first view) / value[t0:t1] += lw[1:] (others)   (:502-507)
+                dst0, src0 = (0, 0) if idx == 0 else (t0, 1)
+                if idx == 0 and t0 != 1:
+                    raise ValueError("the first window must start at frame 1")
+                for k in range(t1 - dst0):
+                    f = dst0 + k
+                    src = lw[src0 + k].reshape(-1)
+                    dstv = value[f].reshape(-1)
+                    ops.axpby_f32_(src, dstv, 1.0, 1.0 if touched[f] else 0.0)
+                    touched[f] = True
+                    count[f] += 1
+            for f in range(N):                                                         # latents = value / count (:511)
+                if count[f]:
+                    ops.axpby_f32_(value[f].reshape(-1), lat[f].reshape(-1), 1.0 / count[f], 0.0)
+        latents_out = lat.reshape(1, N, 4, h, w)
+        frames = latents_out if output_type == "latent" else decode_latents(self.vae, latents_out, N, decode_chunk_size)
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
