@@ -110,7 +110,7 @@ def _cpu_baseline_worker():
                     p.zero_()
     setup = time.time() - t0
     g = torch.Generator().manual_seed(0)
-    Tc, Hc, Wc = 8, 128, 128
+    Tc, Hc, Wc = 8, 256, 256
     x = torch.randn(2, Tc, 8, Hc // 8, Wc // 8, generator=g)
     emb = torch.randn(2, 1, 1024, generator=g)
     ids = torch.tensor([[6.0, 128.0, 0.02]] * 2)
@@ -130,7 +130,7 @@ def _cpu_baseline_worker():
 def cpu_baseline(timeout=420):
     """The CPU oracle (fp32 PyTorch restatement of the reference pipeline, oracle/) on a BOUNDED sample of the same
     workload: ONE denoise step (MOFA-Adapter/ControlNet + UNet, CFG batch 2) of the full-size SVD-XT architecture at
-    8 frames x 128x128, FLOPs counted by torch's FlopCounterMode, converted to the metric's unit through the
+    8 frames x 256x256 (BASELINE config[0] geometry), FLOPs counted by torch's FlopCounterMode, converted to the metric's unit through the
     analytic work model (225.5 TFLOP per denoised frame at 25 f 576x1024).  Runs in a child process
     with a hard timeout so the default bench stays within minutes on any host."""
     import subprocess
@@ -144,7 +144,7 @@ def cpu_baseline(timeout=420):
     cpu_tflops = d["tflop"] / d["dt"]
     return dict(value=cpu_tflops / 225.5, unit="denoised frames/sec", cores=d["cores"], kind="port",
                 sample=(f"oracle (fp32 torch CPU, {d['cores']} threads of {d['avail']} available): one denoise step of the "
-                        f"full-size SVD-XT UNet + MOFA ControlNet at 8 f x 128x128, CFG batch 2 = {d['tflop']:.3f} TFLOP "
+                        f"full-size SVD-XT UNet + MOFA ControlNet at 8 f x 256x256, CFG batch 2 = {d['tflop']:.3f} TFLOP "
                         f"(FlopCounterMode) in {d['dt']:.1f} s = {cpu_tflops:.4f} TFLOP/s (model setup {d['setup']:.0f} s "
                         f"untimed); value = that rate / 225.5 TFLOP per denoised frame at 25 f 576x1024"))
 
@@ -236,8 +236,15 @@ def main():
         avg_s = ig["seconds"] / max(ig["launches"], 1)
         ach = ig["flops"] / ig["seconds"] / 1e12
         at = summ.get("attn_spatial_kernel")
+        traffic = None       # HBM bytes per launch from the committed PMC passes (not collectable live)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01b_igemm_traffic.json")))
+            traffic = dict(hbm_bytes_per_launch=round(tj["hbm_bytes_per_launch"]), source="profiles/r01b_igemm_traffic.json "
+                           "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)")
+        except Exception:  # noqa: BLE001
+            pass
         roofline = dict(kernel="igemm_f16_kernel", bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         launches_per_clip=ig["launches"] // max(args.steps, 1),
                         avg_launch_us=round(avg_s * 1e6, 1),
                         algorithmic_tflop_per_launch=round(ig["flops"] / max(ig["launches"], 1) / 1e12, 5),
