@@ -464,13 +464,15 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
 
     // kernel configurations of the LDS-DMA ring: {tile, K per stage, stages}
     typedef void (*kern_t)(const mofa_igemm_args, const int, const int);
-    struct Cfg { kern_t k; int tile, threads, lds; };
+    struct Cfg { kern_t k; int tm, tn, threads, lds; };
     static const Cfg cfgs[] = {
-        {igemm_f16_kernel<2, 2, 2, 2, 32, 4>, 128, 256, 4 * 256 * 64},     // 0: 128^2, 64-B rows, 3 tiles in flight
-        {igemm_f16_kernel<2, 4, 4, 2, 32, 4>, 256, 512, 4 * 512 * 64},     // 1: 256^2, 64-B rows, 3 tiles in flight
-        {igemm_f16_kernel<2, 2, 2, 2, 64, 2>, 128, 256, 2 * 256 * 128},    // 2: 128^2, 128-B rows, 1 tile in flight
-        {igemm_f16_kernel<2, 4, 4, 2, 64, 2>, 256, 512, 2 * 512 * 128},    // 3: 256^2, 128-B rows, 1 tile in flight
-        {igemm_f16_kernel<2, 2, 2, 2, 64, 3>, 128, 256, 3 * 256 * 128},    // 4: 128^2, 128-B rows, 2 tiles in flight
+        {igemm_f16_kernel<2, 2, 2, 2, 32, 4>, 128, 128, 256, 4 * 256 * 64},    // 0: 128^2, 64-B rows, 3 tiles in flight
+        {igemm_f16_kernel<2, 4, 4, 2, 32, 4>, 256, 256, 512, 4 * 512 * 64},    // 1: 256^2, 64-B rows, 3 tiles in flight
+        {igemm_f16_kernel<2, 2, 2, 2, 64, 2>, 128, 128, 256, 2 * 256 * 128},   // 2: 128^2, 128-B rows, 1 tile in flight
+        {igemm_f16_kernel<2, 4, 4, 2, 64, 2>, 256, 256, 512, 2 * 512 * 128},   // 3: 256^2, 128-B rows, 1 tile in flight
+        {igemm_f16_kernel<2, 2, 2, 2, 64, 3>, 128, 128, 256, 3 * 256 * 128},   // 4: 128^2, 128-B rows, 2 tiles in flight
+        {igemm_f16_kernel<4, 2, 2, 2, 64, 3>, 256, 128, 512, 3 * 384 * 128},   // 5: 256x128, 128-B rows, 2 tiles in flight
+        {igemm_f16_kernel<2, 4, 2, 2, 64, 3>, 128, 256, 512, 3 * 384 * 128},   // 6: 128x256, 128-B rows, 2 tiles in flight
     };
     static int variant = -1;   // -2 = register-staged kernel, -1 unset, otherwise forced cfg (or 100 = auto)
     if (variant == -1) {
@@ -509,7 +511,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
             ci = big ? 3 : 2;
         }
         const Cfg& c = cfgs[ci];
-        const int tilesM = cdiv(a->M, c.tile), tilesN = cdiv(a->N, c.tile);
+        const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
         hipLaunchKernelGGL(c.k, dim3(tilesM * tilesN), dim3(c.threads), c.lds, st, *a, tilesN, tilesM * tilesN);
     }
     MOFA_CHECK_LAUNCH();

@@ -242,22 +242,25 @@ extern "C" int mofa_affine_act_f16(const void* x, const float* scale, const floa
     return MOFA_OK;
 }
 
-// LayerNorm: one wave per token row, row held in registers (C <= 2048).
+// LayerNorm: 16 lanes per token row (4 rows per wave, 16 per workgroup), row held in registers (C <= 1280);
+// reductions are 4 xor-shuffles inside the 16-lane group.
+#define LN_MAXIT 10
+template <int MAXIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, f16* __restrict__ y, int M,
                                                         int C, int ldx, int ldy, float eps,
                                                         const float* __restrict__ rowvec, int rv_div, int rv_mod) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
+    const int l16 = threadIdx.x & 15;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (row >= M) return;
     const int CV = C >> 3;
-    float v[4][8];
+    float v[MAXIT][8];
     const f16* xp = x + (size_t)row * ldx;
     const float* rv = rowvec ? rowvec + (size_t)((row / rv_div) % rv_mod) * C : nullptr;
     float sum = 0.f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int cv = lane + 64 * it;
+    for (int it = 0; it < MAXIT; ++it) {
+        const int cv = l16 + 16 * it;
         if (cv < CV) {
             const f16x8 a = *(const f16x8*)(xp + cv * 8);
 #pragma unroll
@@ -272,12 +275,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
             for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
         }
     }
-    sum = wave_sum(sum);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float mean = sum / (float)C;
     float sq = 0.f;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int cv = lane + 64 * it;
+    for (int it = 0; it < MAXIT; ++it) {
+        const int cv = l16 + 16 * it;
         if (cv < CV) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -286,17 +290,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
             }
         }
     }
-    sq = wave_sum(sq);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
     const float rstd = rsqrtf(sq / (float)C + eps);
     f16* yp = y + (size_t)row * ldy;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int cv = lane + 64 * it;
+    for (int it = 0; it < MAXIT; ++it) {
+        const int cv = l16 + 16 * it;
         if (cv < CV) {
+            const f32x4 g0 = *(const f32x4*)(gamma + cv * 8), g1 = *(const f32x4*)(gamma + cv * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + cv * 8), b1 = *(const f32x4*)(beta + cv * 8 + 4);
             f16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                o[e] = (f16)fmaf((v[it][e] - mean) * rstd, gamma[cv * 8 + e], beta[cv * 8 + e]);
+                o[e] = (f16)fmaf((v[it][e] - mean) * rstd, e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]);
             *(f16x8*)(yp + cv * 8) = o;
         }
     }
@@ -305,11 +312,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 extern "C" int mofa_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, int ldx,
                                   int ldy, float eps, const float* rowvec, int rv_div, int rv_mod,
                                   mofa_stream_t stream) {
-    if (!x || !gamma || !beta || !y || M <= 0 || C <= 0 || C % 8 != 0 || C > 2048 || ldx % 8 != 0 || ldy % 8 != 0)
+    if (!x || !gamma || !beta || !y || M <= 0 || C <= 0 || C % 8 != 0 || C > 16 * 8 * LN_MAXIT || ldx % 8 != 0 || ldy % 8 != 0)
         return MOFA_EINVAL;
     if (rowvec && (rv_div <= 0 || rv_mod <= 0)) return MOFA_EINVAL;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma, beta,
-                       (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
+    const int CV = C / 8;
+    if (CV <= 48)
+        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma,
+                           beta, (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
+    else if (CV <= 80)
+        hipLaunchKernelGGL(layernorm_kernel<5>, dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma,
+                           beta, (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<LN_MAXIT>, dim3(cdiv(M, 16)), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
+                           gamma, beta, (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

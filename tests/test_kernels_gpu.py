@@ -325,3 +325,75 @@ def test_scheduler_kernels_vs_oracle(ops):
     latd = lat.to(DEV).clone()
     ops.cfg_euler_step_(latd, npred.to(DEV).reshape(2 * T * h * w, 4), sigma, sigma_next, 1.0, 3.0)
     _close(latd, ref, tol=1e-5, what="cfg + euler")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# kernels of the landmark / Hybrid / Keypoint paths
+# ---------------------------------------------------------------------------------------------------------
+def test_igemm_conv7x7_relu(ops):
+    from mofa_video_amd.weights import pack_conv3x3, pad_rows
+    n, Cin, Cout, H, W = 2, 64, 1, 11, 9
+    x = _h(n, Cin, H, W, seed=50)
+    w = _h(Cout, Cin, 7, 7, seed=51, scale=0.03)
+    b = torch.randn(Cout, generator=torch.Generator().manual_seed(52))
+    xt = x.permute(0, 2, 3, 1).reshape(n * H * W, Cin).contiguous()
+    out = ops.igemm(xt.to(DEV), pack_conv3x3(pad_rows(w)).to(DEV), pad_rows(b).to(DEV), geom=ops.conv3x3_geom(H, W, ksize=7),
+                    act=3)
+    ref = F.relu(F.conv2d(x.float(), w.float(), b, padding=3)).permute(0, 2, 3, 1).reshape(-1, 1)
+    _close(out[:, :1], ref, what="conv7x7 + relu")
+    assert out[:, 1:].abs().max().item() == 0
+
+
+def test_blend_resize_subsample_axpby(ops):
+    M, C, HW = 6 * 35, 64, 35
+    a, b = _h(M, C, seed=53), _h(M, C, seed=54)
+    w = torch.rand(HW, generator=torch.Generator().manual_seed(55))
+    out = ops.mask_blend(a.to(DEV), b.to(DEV), w.to(DEV), HW)
+    wr = w.repeat(M // HW)[:, None]
+    _close(out, a.float() * wr + b.float() * (1 - wr), tol=1e-3, what="mask blend")
+    lg = _h(M, 8, seed=56, scale=2.0)
+    o2, mk = ops.matting_blend(a.to(DEV), b.to(DEV), lg.to(DEV))
+    m = torch.sigmoid(lg[:, :1].float())
+    _close(o2, a.float() * m + b.float() * (1 - m), tol=1e-3, what="matting blend")
+    _close(mk, m[:, 0], tol=1e-5, what="matting mask")
+    msk = torch.rand(2, 48, 80, generator=torch.Generator().manual_seed(57))
+    for (h2, w2) in [(6, 10), (12, 20), (5, 7)]:
+        ref = F.interpolate(msk[None], (h2, w2), mode="nearest")[0]
+        assert torch.equal(ops.resize_nearest_f32(msk.to(DEV), h2, w2).cpu(), ref)
+    t = _h(3 * 8 * 12, 64, seed=58)
+    sub = ops.subsample_tokens(t.to(DEV), 3, 8, 12, 2)
+    ref = F.interpolate(t.reshape(3, 8, 12, 64).permute(0, 3, 1, 2).float(), scale_factor=0.5).permute(0, 2, 3, 1)
+    assert torch.equal(sub.cpu().float(), ref.reshape(-1, 64))
+    x32 = torch.randn(1000, generator=torch.Generator().manual_seed(59))
+    y32 = torch.randn(1000, generator=torch.Generator().manual_seed(60))
+    got = ops.axpby_f32_(x32.to(DEV), y32.to(DEV).clone(), 0.25, 1.0)
+    _close(got, 0.25 * x32 + y32, tol=1e-6, what="axpby f32")
+    got = ops.axpby_f32_(x32.to(DEV), torch.full((1000,), float("nan"), device=DEV), 0.5, 0.0)   # b == 0 overwrites
+    _close(got, 0.5 * x32, tol=1e-6, what="axpby f32 overwrite")
+
+
+def test_igemm_unclipped_temporal_halo(ops):
+    """MOFA_MODE_CONVT3 with T = 0: the caller supplies halo frames (frame-sharded clips)."""
+    from mofa_video_amd.weights import pack_conv3d_t3
+    T, HW, Cc = 6, 10, 64
+    x = _h(1, Cc, T, HW, 1, seed=61)
+    w = _h(Cc, Cc, 3, 1, 1, seed=62, scale=0.1)
+    full = F.conv3d(x.float(), w.float(), None, padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0)   # [T,HW,C]
+    xt = x[0, :, :, :, 0].permute(1, 2, 0).reshape(T * HW, Cc).contiguous().to(DEV)                  # [T*HW, C]
+    f0, f1 = 2, 5                                                 # this "rank" owns frames 2..4, halo = frames 1 and 5
+    ext = xt[(f0 - 1) * HW:(f1 + 1) * HW].contiguous()
+    out = ops.igemm(ext[HW:], pack_conv3d_t3(w).to(DEV), None, geom=ops.convt3_geom(0, HW), M=(f1 - f0) * HW)
+    _close(out, full[f0:f1].reshape(-1, Cc), what="unclipped temporal conv with halo")
+
+
+def test_attn_temporal_sharded_queries(ops):
+    T, Tq, HW, heads = 7, 3, 9, 2
+    Cc = heads * 64
+    qkv = _h(T * HW, 3 * Cc, seed=63)
+    d = qkv.to(DEV)
+    full = ops.attn_temporal(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], 1, T, HW, heads)
+    f0 = 2
+    q = d[f0 * HW:(f0 + Tq) * HW, :Cc]
+    kv = d[:, Cc:].contiguous()
+    part = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, T, HW, heads, Tq=Tq)
+    assert torch.equal(part, full[f0 * HW:(f0 + Tq) * HW])
