@@ -1,29 +1,33 @@
-// Implicit-GEMM on MFMA for gfx950: every linear / 1x1 conv / 3x3 conv (s1, s2, nearest-2x input) /
+// Implicit-GEMM on MFMA for gfx950: every linear / 1x1 conv / kxk conv (s1, s2, nearest-2x input) /
 // temporal (3,1,1) conv of the SVD UNet, the MOFA-Adapter trunk and the temporal VAE decoder.
 //
 //   out[m, n] = act( s_acc * (sum_tap sum_k X[src(m,tap), k] * W[n, tap*Cin + k] + bias[n] + rowvec[idx(m), n])
 //                    + s1 * R1[m, n] + s2 * R2[m, n] )
 //
-// Output tile 128(M) x 128(N) per 256-thread workgroup (4 waves in 2x2, each 64x64 = 2x2 MFMA 32x32x16 f16
-// tiles, fp32 accumulators).  The MFMA "A" operand is the WEIGHT tile and the "B" operand the ACTIVATION tile, so an
-// accumulator lane owns one output row m (= lane & 31) and 4 consecutive output columns per register quad -> 8-byte
-// epilogue loads/stores along the channel axis.  K is walked tap-major; zero padding of the convolution is realised
+// One PERSISTENT workgroup per CU slot walks output tiles (128x128 with 4 waves, 2 workgroups per CU; or 256x256 with
+// 8 waves, 1 per CU).  Each wave owns MI x 2 MFMA 32x32x16 f16 tiles with fp32 accumulators.  The MFMA "A" operand is
+// the WEIGHT tile and the "B" operand the ACTIVATION tile, so an accumulator lane owns one output row.  K is walked
+// tap-major in steps of 64 (128-byte LDS rows = whole cache lines per row); zero padding of the convolution is realised
 // by sourcing the rows of an out-of-image tap from a zero page.
 //
-// igemm_f16_kernel (default): the K loop is a 4-stage LDS ring filled by direct-to-LDS DMA
-//   (global_load_lds_dwordx4, 16 B per lane, no VGPR staging), K step 32.  Three K tiles are kept in flight; each
-//   iteration waits with a COUNTED s_waitcnt vmcnt (never a drain in steady state) + one raw s_barrier, issues the
-//   tile three steps ahead, then runs 8 MFMAs per wave.  The LDS image is lane-linear (64-byte rows); bank conflicts
-//   of the ds_read_b128 fragment reads are removed by an XOR swizzle applied on the SOURCE address
-//   (chunk ^= (row>>2)&3) and again on the read (cdna guide, rule 21).
-// igemm_regstage_kernel: the first-generation variant (global -> VGPR -> LDS, 2 buffers, K step 64), kept for A/B
-//   (MOFA_IGEMM_REGSTAGE=1).
+// K loop: a 2-stage LDS ring filled by direct-to-LDS DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR staging).
+// The LDS image is lane-linear; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied
+// on the SOURCE address and again on the read (cdna guide, rule 21).  The stream of stages runs ACROSS tiles: the last
+// K step of a tile issues stage 0 of the workgroup's next tile, so the DMA latency of the next tile hides under the
+// epilogue of the current one.  The first wait of the next tile is a COUNTED s_waitcnt vmcnt(T), T = the VMEM
+// operations the epilogue issued after that DMA (its output stores are not drained); T is exact only for interior
+// tiles on the 16-byte path, every other tile waits with vmcnt(0).
+//
+// Epilogue: each wave transposes its 32 x 64 accumulator block through a private 8 KB XOR-swizzled LDS slab (inside the
+// ring stage the K loop has just finished with) so that a lane owns 8 consecutive columns of one row; bias, row vector,
+// residuals, GEGLU product and activation are applied in that layout with 16-byte global accesses.  Residual loads run
+// one pass ahead of the stores (vmcnt retires in order on gfx9: a load issued before a store never waits for it).  The
+// kernel is templated on the epilogue kind (residuals / row vector / GEGLU) so the memory operations per pass are static.
+// Earlier variants (register staging, 64-byte rows, deeper rings, 256x128 tiles) and their measurements:
+// profiles/r01_igemm_config_sweep.md.
 #include <stdlib.h>
 
 #include "common.h"
-
-#define BM 128
-#define BN 128
 
 struct RowGeo {
     int img, oy, ox;  // conv3x3: image index and output pixel; convT3: oy = frame index within its clip
@@ -31,6 +35,17 @@ struct RowGeo {
 };
 
 __device__ __attribute__((aligned(128))) f16 g_zero_page[128];  // source of out-of-image taps / rows beyond M
+
+#ifdef MOFA_IGEMM_TRACE   // tools/igemm_trace.hip: per-workgroup tick sums: [0] first-tile prologue, [1] K loops, [2] epilogues, [3] tiles
+__device__ unsigned long long g_trace[8 * 1024];
+#define TRACE_DECL unsigned long long tr_t = __builtin_readcyclecounter(), tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define TRACE_ADD(slot) do { const unsigned long long t__ = __builtin_readcyclecounter(); tr_acc[slot] += t__ - tr_t; tr_t = t__; } while (0)
+#define TRACE_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 1024) for (int i__ = 0; i__ < 8; ++i__) g_trace[blockIdx.x * 8 + i__] = tr_acc[i__]; } while (0)
+#else
+#define TRACE_DECL do { } while (0)
+#define TRACE_ADD(slot) do { } while (0)
+#define TRACE_FLUSH() do { } while (0)
+#endif
 
 __device__ __forceinline__ RowGeo make_geo(const mofa_igemm_args& a, int m) {
     RowGeo g;
@@ -67,133 +82,229 @@ __device__ __forceinline__ const f16* x_src(const mofa_igemm_args& a, const RowG
     }
 }
 
-// XCD-aware (bijective) workgroup remap: consecutive tile ids (same activation row block, successive weight column
-// blocks) land on the same XCD so the activation tile is served from that XCD's L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    const int q = nwg >> 3, r = nwg & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+// XCD-aware persistent tile walk: the hardware deals workgroup ids round-robin over the 8 XCDs, so workgroup b lives on
+// XCD b & 7.  Each XCD gets a CONTIGUOUS range of tile ids (bijective split of ntiles into 8 ranges) and its resident
+// workgroups walk that range with stride (workgroups per XCD): at any time one XCD works on neighbouring tiles (same
+// activation row block, successive weight column blocks) and the activation tile is served from that XCD's L2.
+struct TileWalk {
+    int start, count, local, stride;
+    __device__ __forceinline__ void init(int ntiles) {
+        const int xcd = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
+        start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        count = q + (xcd < r ? 1 : 0);
+        local = blockIdx.x >> 3;
+        stride = gridDim.x >> 3;
+    }
+};
+
+__device__ int g_igemm_stagger = 0;   // start delay of the upper half of the grid, units of 512 clocks
+
+#define EPI_R1 1
+#define EPI_R2 2
+#define EPI_RV 4
+#define EPI_GEGLU 8
+
+__device__ __forceinline__ void glds16(const f16* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Every wait of the K loop sits right in front of an s_barrier that hands an LDS stage to another writer (the next
+// DMA, the epilogue slabs).  It therefore also drains lgkmcnt: hipcc is free to sink the wait for the wave's last
+// ds_reads (and the MFMAs consuming them) below a raw s_barrier, and a wave that is past the barrier would then
+// overwrite LDS that those reads have not returned from yet.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// wait until at most t VMEM operations are outstanding, t rounded DOWN to an encodable step (waiting longer is safe)
+__device__ __forceinline__ void wait_vmcnt_le(int t) {
+    if (t >= 48) wait_vmcnt<48>();
+    else if (t >= 32) wait_vmcnt<32>();
+    else if (t >= 24) wait_vmcnt<24>();
+    else if (t >= 16) wait_vmcnt<16>();
+    else if (t >= 8) wait_vmcnt<8>();
+    else if (t >= 4) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
 }
 
 // ---- epilogue -----------------------------------------------------------------------------------------------------
-// The accumulator layout (lane = one row, 4 consecutive columns per register quad) would give 8-byte global accesses
-// scattered over 32 rows per instruction.  Instead each wave transposes its 32 x (NJ*32) block through a private LDS
-// slab (the K ring is free by then): phase 1 writes s_acc*(acc + bias + rowvec) in fp32 in fragment layout
-// (ds_write_b128, rows padded to a 16-byte-odd stride), phase 2 re-reads it row-wise so that a lane owns 8 consecutive
-// columns of one row: residuals are loaded and the result stored with 16-byte accesses, consecutive lanes covering
-// consecutive 16-byte pieces of the same output row (whole 64/128-byte segments per row).
-// (mrow0, ncol0) = origin of this wave's MI x NJ block of 32x32 accumulator tiles; slab = this wave's LDS slab.
-#define EPI_COLS_MAX 64
-#define EPI_STRIDE (EPI_COLS_MAX * 4 + 16)              // bytes per staged row (fp32) -- 272: conflict-free both ways
-#define EPI_SLAB_BYTES (32 * EPI_STRIDE)
+// slab: 32 rows x 64 fp32 columns = 256 B per row, 16-byte chunk c of row r stored at chunk c ^ (r & 15): the
+// fragment-layout ds_write_b128 (lanes = 32 rows x 2 adjacent chunks) and the row-wise ds_read_b128 (lanes = 8 rows x
+// 8 even chunks) are both bank-conflict free.
+#define EPI_SLAB_BYTES 8192
+__device__ __forceinline__ int slab_off(int row, int chunk) { return row * 256 + ((chunk ^ (row & 15)) << 4); }
 
-template <int MI, int NJ>
-__device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 (&acc)[MI][NJ], int mrow0, int ncol0,
-                                               int lane, char* slab) {
-    static_assert(NJ == 2, "epilogue slab is sized for 64 staged columns");
+struct PassLoads {
+    f16x8 t1, t2;
+    f32x4 rv0, rv1;
+};
+
+// lane-constant bias registers: plain: bias[n .. n+8); GEGLU: value columns [0..1], gate columns [2..3].
+// Loaded one tile AHEAD (before the prologue / after the previous tile's epilogue) and "touched" (bias_touch) at the
+// tile's last K step, where the K loop's own vmcnt(0) has just drained everything: hipcc's waitcnt insertion then
+// sees them as complete and puts no vmcnt(0) into the epilogue (which would also drain the next tile's DMA).
+template <int EPI>
+__device__ __forceinline__ void load_bias(const mofa_igemm_args& a, int ncol0, int lane, f32x4 (&b)[4]) {
+    constexpr bool GEGLU = (EPI & EPI_GEGLU) != 0;
+    const f32x4 z = {0, 0, 0, 0};
+    b[0] = z; b[1] = z; b[2] = z; b[3] = z;
+    if (!a.bias) return;
+    if (GEGLU) {
+        int nv = ncol0 + (lane & 3) * 8;                           // N is a multiple of 64 here
+        nv = nv < a.N ? nv : 0;                                    // columns beyond N are never stored
+        b[0] = *(const f32x4*)(a.bias + nv); b[1] = *(const f32x4*)(a.bias + nv + 4);
+        b[2] = *(const f32x4*)(a.bias + nv + 32); b[3] = *(const f32x4*)(a.bias + nv + 36);
+    } else {
+        const int n = ncol0 + (lane & 7) * 8;
+        const int n_lo = n + 4 <= a.N ? n : 0;                     // columns beyond N are never stored
+        const int n_hi = n + 8 <= a.N ? n + 4 : n_lo;
+        b[0] = *(const f32x4*)(a.bias + n_lo); b[1] = *(const f32x4*)(a.bias + n_hi);
+    }
+}
+template <int EPI>
+__device__ __forceinline__ void bias_touch(f32x4 (&b)[4]) {
+    if (EPI & EPI_GEGLU) asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    else asm volatile("" : "+v"(b[0]), "+v"(b[1]));
+}
+
+// (mrow0, ncol0) = origin of this wave's MI x 2 block of 32x32 accumulator tiles; slab = this wave's LDS slab.
+// WIDE: every row start of out / r1 / r2 is 16-byte aligned and N % 8 == 0 (a piece is whole or empty).
+#ifdef MOFA_IGEMM_TRACE
+#define EPI_TRACE_PARAMS , unsigned long long& tr_t, unsigned long long (&tr_acc)[8]
+#define EPI_TRACE_ARGS , tr_t, tr_acc
+#else
+#define EPI_TRACE_PARAMS
+#define EPI_TRACE_ARGS
+#endif
+template <int MI, int EPI, bool WIDE>
+__device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 (&acc)[MI][2], const int mrow0,
+                                               const int ncol0, const int lane, char* slab, f32x4 (&bias)[4] EPI_TRACE_PARAMS) {
+    constexpr bool GEGLU = (EPI & EPI_GEGLU) != 0, R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0,
+                   RV = (EPI & EPI_RV) != 0;
+    constexpr int CPR = GEGLU ? 4 : 8;          // 8-column pieces per output row of this wave
+    constexpr int RPP = 64 / CPR;               // rows per pass
+    constexpr int P = 32 / RPP;                 // passes per 32-row accumulator tile
+    constexpr int S = MI * P;
     const int l31 = lane & 31, lh = lane >> 5;
+    const int lrow = lane / CPR, lc = lane % CPR;
     const f16* r1 = (const f16*)a.r1;
     const f16* r2 = (const f16*)a.r2;
     f16* out = (f16*)a.out;
-    const bool geglu = a.act == MOFA_ACT_GEGLU_PAIR;
-    const int ocols = geglu ? 32 : 64;                   // staged output columns of this wave
-    const int ocol0 = geglu ? ncol0 / 2 : ncol0;         // first output column
-    const int nout = geglu ? a.N / 2 : a.N;              // number of valid output columns
-    // 16-byte path needs every row start 16-byte aligned
-    const bool wide = ((a.ldo & 7) == 0) && (!r1 || (a.ldr1 & 7) == 0) && (!r2 || (a.ldr2 & 7) == 0) &&
-                      ((((size_t)a.out) & 15) == 0) && ((((size_t)a.r1) & 15) == 0) && ((((size_t)a.r2) & 15) == 0);
+    const int nout = GEGLU ? a.N / 2 : a.N;
+    const int n = (GEGLU ? ncol0 / 2 : ncol0) + lc * 8;       // first of this lane's 8 output columns
+    const bool c8 = n + 8 <= nout, c4 = n + 4 <= nout;        // N % 4 == 0: a piece is whole, half or empty
+
+    // Residual / row-vector loads: UNCONDITIONAL 16-byte (8-byte off the wide path) loads from clamped addresses (rows
+    // beyond M and pieces beyond N are never stored), a whole 32-row accumulator tile (P passes) at a time, and one
+    // explicit wait + idle slots before the first consumer.  Compiler-placed waits are avoided on purpose: with the
+    // s_waitcnt vmcnt(0) directly in front of the first VALU read (two ds_read_b128 still returning) that read
+    // intermittently saw the pre-load register contents in lanes 48..63 on MI355X (tools/igemm_det.hip: 7 of 7 repeat
+    // launches differed, always rows 6/7 of a pass, dwords 0/2 of the loaded quad).
+    constexpr int REGS_PER_TILE = P * ((R1 ? 4 : 0) + (R2 ? 4 : 0) + (RV ? 8 : 0));
+    constexpr bool AHEAD = REGS_PER_TILE > 0 && REGS_PER_TILE <= 32;   // next tile's loads before this tile's stores
+    const int n_lo = c4 ? n : 0, n_hi = c8 ? n + 4 : n_lo;
+    auto issue_tile_loads = [&](int i, PassLoads (&L)[P]) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int m = mrow0 + i * 32 + p * RPP + lrow;
+            m = m < a.M ? m : a.M - 1;
+            if (R1) {
+                const f16* q = r1 + (size_t)m * a.ldr1;
+                if (WIDE) L[p].t1 = *(const f16x8*)(q + n_lo);
+                else {
+                    const f16x4 lo = *(const f16x4*)(q + n_lo), hi = *(const f16x4*)(q + n_hi);
+                    L[p].t1 = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+            if (R2) {
+                const f16* q = r2 + (size_t)m * a.ldr2;
+                if (WIDE) L[p].t2 = *(const f16x8*)(q + n_lo);
+                else {
+                    const f16x4 lo = *(const f16x4*)(q + n_lo), hi = *(const f16x4*)(q + n_hi);
+                    L[p].t2 = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+            }
+            if (RV) {
+                const int idx = ((m / a.rv_div) * a.rv_mul + (m % a.rv_mod_in)) % a.rv_mod_out;
+                const float* q = a.rowvec + (size_t)idx * a.N;
+                L[p].rv0 = *(const f32x4*)(q + n_lo);
+                L[p].rv1 = *(const f32x4*)(q + n_hi);
+            }
+        }
+    };
+    auto settle = [&](PassLoads (&L)[P]) {               // all loads of the tile have landed; keep consumers away
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (R1 && R2 && RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1), "+v"(L[p].t2), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+            else if (R1 && R2) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1), "+v"(L[p].t2) :: "memory");
+            else if (R1 && RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+            else if (R2 && RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t2), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+            else if (R1) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1) :: "memory");
+            else if (R2) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t2) :: "memory");
+            else if (RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+        }
+    };
+
+    TRACE_ADD(4);
+    // The three scale factors live in VGPRs on purpose.  As SGPR operands hipcc folds (s_acc, s1) into one SGPR pair
+    // feeding v_pk_mul_f32 / v_pk_fma_f32 with op_sel cross terms, and on MI355X (two workgroups per CU) that code
+    // intermittently dropped the s1 * r1 term of output column 4 of a piece in lanes 48..63 (tools/igemm_det.hip: 7 of 7
+    // repeat launches differed; with VGPR operands 0 of 7 for every epilogue kind).
+    float s1v = a.s1, s2v = a.s2, saccv = a.s_acc;
+    asm volatile("" : "+v"(s1v), "+v"(s2v), "+v"(saccv));
+    PassLoads LA[P], LB[P];                               // this tile's / (AHEAD) the next tile's loads
+    if (REGS_PER_TILE > 0) issue_tile_loads(0, LA);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        // ---------------- phase 1: fragment layout -> slab ----------------
-        {
-            const int m = mrow0 + i * 32 + l31;
-            const float* rv = nullptr;
-            if (a.rowvec && m < a.M) {
-                const int idx = ((m / a.rv_div) * a.rv_mul + (m % a.rv_mod_in)) % a.rv_mod_out;
-                rv = a.rowvec + (size_t)idx * a.N;
+        // ---- phase 1: raw accumulators, fragment layout -> slab (same-wave DS operations execute in order) ----
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                *(f32x4*)(slab + slab_off(l31, j * 8 + 2 * q + lh)) = v;
             }
-            if (geglu) {
+        TRACE_ADD(5);
+        PassLoads (&L)[P] = (AHEAD && (i & 1)) ? LB : LA;
+        if (REGS_PER_TILE > 0) {
+            if (!AHEAD && i > 0) issue_tile_loads(i, LA);
+            settle(L);
+            // the next tile's loads go out before this tile's stores and so never wait for them
+            if (AHEAD && i + 1 < MI) issue_tile_loads(i + 1, (i & 1) ? LA : LB);
+        }
+        // ---- phase 2: P passes of RPP rows; a lane owns 8 consecutive output columns of one row ----
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int nv = ncol0 + 8 * q + 4 * lh;          // value column in the interleaved N space
-                    f32x4 bv = {0, 0, 0, 0}, bg = {0, 0, 0, 0};
-                    if (a.bias && nv < a.N) { bv = *(const f32x4*)(a.bias + nv); bg = *(const f32x4*)(a.bias + nv + 32); }
-                    f32x4 o;
+        for (int p = 0; p < P; ++p) {
+            const int row = p * RPP + lrow;
+            const int m = mrow0 + i * 32 + row;
+            float v[8];
+            {
+                const f32x4 v0 = *(const f32x4*)(slab + slab_off(row, 2 * lc));
+                const f32x4 v1 = *(const f32x4*)(slab + slab_off(row, 2 * lc + 1));
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float v = a.s_acc * (acc[i][0][4 * q + e] + bv[e]);
-                        const float g = a.s_acc * (acc[i][1][4 * q + e] + bg[e]);
-                        o[e] = v * gelu_erf_f(g);
-                    }
-                    *(f32x4*)(slab + l31 * EPI_STRIDE + (8 * q + 4 * lh) * 4) = o;
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+            }
+            if (GEGLU) {
+                const f32x4 g0 = *(const f32x4*)(slab + slab_off(row, 8 + 2 * lc));
+                const f32x4 g1 = *(const f32x4*)(slab + slab_off(row, 9 + 2 * lc));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = saccv * (v[e] + bias[0][e]) * gelu_erf_f(saccv * (g0[e] + bias[2][e]));
+                    v[4 + e] = saccv * (v[4 + e] + bias[1][e]) * gelu_erf_f(saccv * (g1[e] + bias[3][e]));
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = ncol0 + j * 32 + 8 * q + 4 * lh;
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
-                        if (n < a.N) {
-                            if (a.bias) { const f32x4 b = *(const f32x4*)(a.bias + n); v += b; }
-                            if (rv) { const f32x4 b = *(const f32x4*)(rv + n); v += b; }
-                        }
-                        v *= a.s_acc;
-                        *(f32x4*)(slab + l31 * EPI_STRIDE + (j * 32 + 8 * q + 4 * lh) * 4) = v;
-                    }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave DS ops are ordered; make the data visible
-        // ---------------- phase 2: row-wise, 8 columns per lane per pass ----------------
-        {
-            const int cpr = ocols >> 3;                      // 16-byte (8-column) pieces per row: 8 or 4
-            const int rpp = 64 / cpr;                        // rows covered per pass: 8 or 16
-            const int lrow = lane / cpr, lcol = (lane - lrow * cpr) * 8;
-            for (int r0 = 0; r0 < 32; r0 += rpp) {
-                const int row = r0 + lrow;
-                const int m = mrow0 + i * 32 + row;
-                const int n = ocol0 + lcol;
-                if (m >= a.M || n >= nout) continue;
-                const f32x4 v0 = *(const f32x4*)(slab + row * EPI_STRIDE + lcol * 4);
-                const f32x4 v1 = *(const f32x4*)(slab + row * EPI_STRIDE + lcol * 4 + 16);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                const bool full = wide && (n + 8 <= nout);
-                const int cnt = (n + 8 <= nout) ? 8 : 4;     // N % 4 == 0: a piece is whole, half, or empty
-                if (r1) {
-                    const f16* p = r1 + (size_t)m * a.ldr1 + n;
-                    if (full) {
-                        const f16x8 t = *(const f16x8*)p;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += a.s1 * (float)t[e];
-                    } else {
-                        const f16x4 t = *(const f16x4*)p;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += a.s1 * (float)t[e];
-                        if (cnt == 8) {
-                            const f16x4 u = *(const f16x4*)(p + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[4 + e] += a.s1 * (float)u[e];
-                        }
-                    }
-                }
-                if (r2) {
-                    const f16* p = r2 + (size_t)m * a.ldr2 + n;
-                    if (full) {
-                        const f16x8 t = *(const f16x8*)p;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += a.s2 * (float)t[e];
-                    } else {
-                        const f16x4 t = *(const f16x4*)p;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += a.s2 * (float)t[e];
-                        if (cnt == 8) {
-                            const f16x4 u = *(const f16x4*)(p + 4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[4 + e] += a.s2 * (float)u[e];
-                        }
-                    }
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = v[e] + bias[0][e], x1 = v[4 + e] + bias[1][e];
+                    if (RV) { x0 += L[p].rv0[e]; x1 += L[p].rv1[e]; }
+                    x0 *= saccv; x1 *= saccv;
+                    if (R1) { x0 += s1v * (float)L[p].t1[e]; x1 += s1v * (float)L[p].t1[4 + e]; }
+                    if (R2) { x0 += s2v * (float)L[p].t2[e]; x1 += s2v * (float)L[p].t2[4 + e]; }
+                    v[e] = x0; v[4 + e] = x1;
                 }
                 if (a.act == MOFA_ACT_SILU) {
 #pragma unroll
@@ -202,57 +313,51 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
                 }
+            }
+            if (m < a.M && c4) {
                 f16* po = out + (size_t)m * a.ldo + n;
-                if (full) {
+                if (WIDE) {
                     f16x8 o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
                     *(f16x8*)po = o;
                 } else {
-                    f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                    const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
                     *(f16x4*)po = o;
-                    if (cnt == 8) {
-                        f16x4 o2 = {(f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+                    if (c8) {
+                        const f16x4 o2 = {(f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
                         *(f16x4*)(po + 4) = o2;
                     }
                 }
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab is rewritten by the next m-tile
+        TRACE_ADD(6);
     }
 }
 
 // =====================================================================================================================
-// default kernel: LDS ring fed by global_load_lds, counted vmcnt.  Templated on the wave grid (WM x WN waves) and the
-// per-wave block of MFMA tiles (MI x NJ of 32x32): <2,2,2,2> = 128x128 tile / 256 threads, <2,4,4,2> = 256x256 / 512.
+// the kernel.  WM x WN waves, each MI x 2 MFMA tiles: <2,2,2> = 128x128 tile / 256 threads, <2,4,4> = 256x256 / 512.
 // =====================================================================================================================
-__device__ __forceinline__ void glds16(const f16* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// BKS = K per ring stage (32: 64-byte LDS rows, one DMA instruction = 16 rows; 64: 128-byte rows = whole cache lines,
-// one DMA instruction = 8 rows).  NST = ring stages (NST-1 tiles in flight).
-template <int WM, int WN, int MI, int NJ, int BKS, int NST>
+template <int WM, int WN, int MI, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_igemm_args a, const int tilesN,
-                                                                    const int nwg) {
+                                                                 const int ntiles) {
+    constexpr int NJ = 2;
     constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
-    constexpr int RB = BKS * 2;                                    // LDS row bytes
-    constexpr int RPI = 1024 / RB;                                 // rows per DMA instruction
-    constexpr int SPR = RB / 16;                                   // 16-byte slots per row
-    constexpr int SWS = (BKS == 32) ? 2 : 1;                       // swizzle term = (row >> SWS) & (SPR-1)
-    constexpr int XI = TBM / RPI / NW, WI = TBN / RPI / NW;        // DMA instructions per wave per stage
+    constexpr int BKS = 64, RB = 128;                              // K per stage, LDS row bytes
+    constexpr int XI = TBM / 8 / NW, WI = TBN / 8 / NW;            // DMA instructions (8 rows each) per wave per stage
     constexpr int SXB = TBM * RB, STB = SXB + TBN * RB;            // stage bytes: X part, total
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY shared object (cdna guide trap (a))
+    static_assert(NW * EPI_SLAB_BYTES <= STB, "epilogue slabs must fit in one ring stage");
+    constexpr bool GEGLU = (EPI & EPI_GEGLU) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY shared object: 2 stages
 
-    const int bid = xcd_remap(blockIdx.x, nwg);
-    const int tm = bid / tilesN, tn = bid - tm * tilesN;
-    const int m0 = tm * TBM, n0 = tn * TBN;
+    TRACE_DECL;
+    TileWalk walk;
+    walk.init(ntiles);
+    if (walk.local >= walk.count) return;                          // whole workgroup idle
+    // co-resident workgroups (second half of each XCD's share of the grid) start half a K step late: two workgroups
+    // of one CU then alternate DMA wait and MFMA phases instead of colliding in both
+    if (g_igemm_stagger > 0 && (int)(blockIdx.x >> 3) >= (int)(gridDim.x >> 4))
+        for (int i = 0; i < g_igemm_stagger; ++i) __builtin_amdgcn_s_sleep(8);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,32 +368,42 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
     const int kpt = a.Cin / BKS;         // K stages per tap
     const int nk = taps * kpt;
     const size_t Ktot = (size_t)taps * a.Cin;
+    const bool wide = ((a.ldo & 7) == 0) && ((a.N & 7) == 0) && (!(EPI & EPI_R1) || (a.ldr1 & 7) == 0) &&
+                      (!(EPI & EPI_R2) || (a.ldr2 & 7) == 0) && ((((size_t)a.out) & 15) == 0) &&
+                      ((((size_t)a.r1) & 15) == 0) && ((((size_t)a.r2) & 15) == 0);
+    // VMEM operations an interior tile's epilogue issues (per pass: residual / row-vector loads + 1 store)
+    constexpr int EPI_PASSES = MI * (GEGLU ? 2 : 4);
+    const int epi_ops = EPI_PASSES * (1 + ((EPI & EPI_R1) ? 1 : 0) + ((EPI & EPI_R2) ? 1 : 0) + ((EPI & EPI_RV) ? 2 : 0));
 
-    // ---- DMA mapping: one global_load_lds instruction fills RPI rows (lane -> row lane / SPR, slot lane % SPR).
-    //      The slot a lane fills holds source chunk  c = slot ^ ((row >> SWS) & (SPR-1))  (swizzle on the SOURCE
-    //      address; the LDS image stays lane-linear) -> conflict-free ds_read_b128 fragment reads.
+    // ---- DMA mapping: one global_load_lds instruction fills 8 rows (lane -> row lane / 8, 16-byte slot lane % 8).
+    //      The slot a lane fills holds source chunk  c = slot ^ ((row >> 1) & 7)  (swizzle on the SOURCE address; the
+    //      LDS image stays lane-linear) -> conflict-free ds_read_b128 fragment reads.
     RowGeo geo[XI];
     int xoff[XI];
     const f16* wsrc[WI];
+    const f16* xs[XI];
+    int m0 = 0, n0 = 0, itap = 0, ikc = 0, ksw = 0;   // tile origin; position of the NEXT stage to issue
 #pragma unroll
     for (int q = 0; q < XI; ++q) {
-        const int row = (wave * XI + q) * RPI + lane / SPR;
-        geo[q] = make_geo(a, m0 + row);
-        xoff[q] = ((lane % SPR) ^ ((row >> SWS) & (SPR - 1))) * 8;
+        const int row = (wave * XI + q) * 8 + (lane >> 3);
+        xoff[q] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        xs[q] = nullptr;
     }
+    auto setup = [&](int tile) {
+        const int tm = tile / tilesN, tn = tile - tm * tilesN;
+        m0 = tm * TBM; n0 = tn * TBN;
 #pragma unroll
-    for (int q = 0; q < WI; ++q) {
-        const int row = (wave * WI + q) * RPI + lane / SPR;
-        int n = n0 + row;
-        n = n < a.N ? n : a.N - 1;
-        wsrc[q] = (const f16*)a.w + (size_t)n * Ktot + ((lane % SPR) ^ ((row >> SWS) & (SPR - 1))) * 8;
-    }
-    const f16* xs[XI];
+        for (int q = 0; q < XI; ++q) geo[q] = make_geo(a, m0 + (wave * XI + q) * 8 + (lane >> 3));
 #pragma unroll
-    for (int q = 0; q < XI; ++q) xs[q] = nullptr;
-    int itap = 0, ikc = 0;   // position of the NEXT tile to issue
-
-    auto issue = [&](int ks, int stage) {
+        for (int q = 0; q < WI; ++q) {
+            const int row = (wave * WI + q) * 8 + (lane >> 3);
+            int n = n0 + row;
+            n = n < a.N ? n : a.N - 1;
+            wsrc[q] = (const f16*)a.w + (size_t)n * Ktot + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        }
+        itap = 0; ikc = 0; ksw = 0;
+    };
+    auto issue = [&](int stage) {
         if (ikc == 0) {
 #pragma unroll
             for (int q = 0; q < XI; ++q) xs[q] = x_src(a, geo[q], itap);
@@ -300,154 +415,113 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
             glds16(s, sb + (wave * XI + q) * 1024);
         }
 #pragma unroll
-        for (int q = 0; q < WI; ++q) glds16(wsrc[q] + (size_t)ks * BKS, sb + SXB + (wave * WI + q) * 1024);
+        for (int q = 0; q < WI; ++q) glds16(wsrc[q] + (size_t)ksw * BKS, sb + SXB + (wave * WI + q) * 1024);
+        ++ksw;
         if (++ikc == kpt) { ikc = 0; ++itap; }
     };
 
-    f32x16 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    constexpr int D = NST - 1;
-    constexpr int OPS = XI + WI;                          // DMA ops per tile per wave
-    for (int t = 0; t < D && t < nk; ++t) issue(t, t);
-
-    const int fsw = (l31 >> SWS) & (SPR - 1);             // read-side swizzle term is lane-constant
+    const int fsw = (l31 >> 1) & 7;                       // read-side swizzle term is lane-constant
     const int xrow = (wm * MI * 32 + l31) * RB;           // byte offsets of this lane's fragment rows
     const int wrow = SXB + (wn * NJ * 32 + l31) * RB;
 
-    for (int ks = 0; ks < nk; ++ks) {
-        // tile ks must have landed; tiles ks+1 .. ks+D-1 (if they exist) may stay in flight
-        const int rem = nk - 1 - ks;
-        if (D >= 3 && rem >= 2) wait_vmcnt<2 * OPS>();
-        else if (D >= 2 && rem >= 1) wait_vmcnt<OPS>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                     // all waves' parts of tile ks landed; buffer (ks-1)%NST is free
-        if (ks + D < nk) issue(ks + D, (ks + D) % NST);
-        const char* sb = smem + (ks % NST) * STB;
-#pragma unroll
-        for (int kk = 0; kk < BKS / 16; ++kk) {
-            const int slot = ((kk * 2 + lh) ^ fsw) * 16;
-            f16x8 xf[MI], wf[NJ];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8*)(sb + xrow + i * 32 * RB + slot);
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) wf[j] = *(const f16x8*)(sb + wrow + j * 32 * RB + slot);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
+    f32x4 bias[4];
+    setup(walk.start + walk.local);
+    {
+        int lane_b = lane;
+        asm volatile("" : "+v"(lane_b));                  // (recomputed per tile, not kept in VGPRs across the K loop)
+        load_bias<EPI>(a, n0 + wn * NJ * 32, lane_b, bias);
     }
-    __syncthreads();                                      // every wave is done with the ring: reuse it as epilogue slabs
-    igemm_epilogue<MI, NJ>(a, acc, m0 + wm * MI * 32, n0 + wn * NJ * 32, lane, smem + wave * EPI_SLAB_BYTES);
-}
-
-// =====================================================================================================================
-// first-generation kernel: register-staged, 2 LDS buffers, K step 64 (kept for A/B: MOFA_IGEMM_REGSTAGE=1)
-// =====================================================================================================================
-#define BK 64
-#define LDSS 72  // LDS row stride in halves (64 + 8 pad) = 144 B
-#define REGSTAGE_LDS_BYTES (2 * (BM + BN) * LDSS * 2)
-
-__global__ __launch_bounds__(256, 2) void igemm_regstage_kernel(const mofa_igemm_args a, const int tilesN, const int nwg) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    f16* sX = (f16*)smem;             // [2][BM][LDSS]
-    f16* sW = sX + 2 * BM * LDSS;     // [2][BN][LDSS]
-
-    const int bid = xcd_remap(blockIdx.x, nwg);
-    const int tm = bid / tilesN, tn = bid - tm * tilesN;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, lh = lane >> 5;
-
-    const int taps = (a.mode == MOFA_MODE_CONV3X3) ? (a.ksize > 0 ? a.ksize * a.ksize : 9) : (a.mode == MOFA_MODE_CONVT3 ? 3 : 1);
-    const int kpt = a.Cin / BK;
-    const int nk = taps * kpt;
-    const size_t Ktot = (size_t)taps * a.Cin;
-
-    const int lcol = tid & 7, lrow = tid >> 3;
-    RowGeo geo[4];
-    const f16* wrow[4];
+    issue(0);
+    int par = 0;            // ring stage holding K step 0 of the current tile
+    int allow = 0;          // VMEM operations that may stay outstanding at the first wait of the current tile
+    bool first = true;
+    for (;;) {
+        const int m0c = m0, n0c = n0;                     // the tile being computed (setup() moves on to the next)
+        f32x16 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        geo[i] = make_geo(a, m0 + lrow + 32 * i);
-        int n = n0 + lrow + 32 * i;
-        n = n < a.N ? n : a.N - 1;
-        wrow[i] = (const f16*)a.w + (size_t)n * Ktot + lcol * 8;
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        auto compute = [&](int cur) {
+            const char* sb = smem + cur * STB;
+#pragma unroll
+            for (int kk = 0; kk < BKS / 16; ++kk) {
+                const int slot = ((kk * 2 + lh) ^ fsw) * 16;
+                f16x8 xf[MI], wf[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8*)(sb + xrow + i * 32 * RB + slot);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) wf[j] = *(const f16x8*)(sb + wrow + j * 32 * RB + slot);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+        };
+        // K steps 0 .. nk-2: wait for the only DMA in flight (at step 0 the previous epilogue's stores may stay
+        // outstanding), one barrier (all waves' parts landed; the other stage is free), refill, multiply
+        for (int ks = 0; ks < nk - 1; ++ks) {
+            if (ks == 0) wait_vmcnt_le(allow); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (ks == 0) TRACE_ADD(0);               // bucket 0: waiting for a tile's first stage
+            const int cur = (par + ks) & 1;
+            issue(cur ^ 1);
+            compute(cur);
+        }
+        // last K step (peeled: the set-up of the next tile stays out of the steady-state loop)
+        const int last = (par + nk - 1) & 1;
+        if (nk == 1) wait_vmcnt_le(allow); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (nk == 1) TRACE_ADD(0);
+        bias_touch<EPI>(bias);                            // landed long ago (loaded a tile ahead); see load_bias
+        walk.local += walk.stride;
+        const bool has_next = walk.local < walk.count;
+        if (has_next) {                                   // stage 0 of the next tile flies during the epilogue
+            setup(walk.start + walk.local);
+            issue(last ^ 1);
+        } else {                                          // same VMEM operation count on both paths (static waitcnts)
+#pragma unroll
+            for (int q = 0; q < XI + WI; ++q)
+                glds16((const f16*)g_zero_page, smem + (last ^ 1) * STB + (wave * (XI + WI) + q) * 1024);
+        }
+        asm volatile("" ::: "memory");                    // epilogue loads stay behind the DMA (the count assumes it)
+        compute(last);
+        wait_lds();
+        __builtin_amdgcn_s_barrier();                     // every wave is done reading the last stage: it becomes slabs
+        TRACE_ADD(1);
+        char* slab = smem + last * STB + wave * EPI_SLAB_BYTES;
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        if (wide) igemm_epilogue<MI, EPI, true>(a, acc, m0c + wm * MI * 32, n0c + wn * NJ * 32, lane_e, slab, bias EPI_TRACE_ARGS);
+        else igemm_epilogue<MI, EPI, false>(a, acc, m0c + wm * MI * 32, n0c + wn * NJ * 32, lane_e, slab, bias EPI_TRACE_ARGS);
+        TRACE_ADD(2);
+#ifdef MOFA_IGEMM_TRACE
+        tr_acc[3] += 1;
+#endif
+        first = false;
+        if (!has_next) break;
+        // counted wait only when every epilogue memory instruction certainly executed with at least one lane
+        {                                                 // bias of the next tile (n0 is already the next tile's)
+            int lane_b = lane;
+            asm volatile("" : "+v"(lane_b));
+            load_bias<EPI>(a, n0 + wn * NJ * 32, lane_b, bias);
+        }
+        allow = (wide && m0c + TBM <= a.M && n0c + TBN <= a.N) ? epi_ops + (a.bias ? (GEGLU ? 4 : 2) : 0) : 0;
+        par = last ^ 1;
     }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    const f16* xs[4];
-    f16x8 gx[4], gw[4];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    auto load_tile = [&](int ks) {
-        const int tap = ks / kpt, kc = ks - tap * kpt;
-        if (kc == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xs[i] = x_src(a, geo[i], tap);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gx[i] = xs[i] ? *(const f16x8*)(xs[i] + kc * BK + lcol * 8) : zero8;
-            gw[i] = *(const f16x8*)(wrow[i] + (size_t)ks * BK);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *(f16x8*)&sX[(buf * BM + lrow + 32 * i) * LDSS + lcol * 8] = gx[i];
-            *(f16x8*)&sW[(buf * BN + lrow + 32 * i) * LDSS + lcol * 8] = gw[i];
-        }
-    };
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) load_tile(ks + 1);
-        const f16* bx = sX + (buf * BM + wm * 64 + l31) * LDSS + lh * 8;
-        const f16* bw = sW + (buf * BN + wn * 64 + l31) * LDSS + lh * 8;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f16x8 xf[2], wf[2];
-            xf[0] = *(const f16x8*)(bx + kk * 16);
-            xf[1] = *(const f16x8*)(bx + 32 * LDSS + kk * 16);
-            wf[0] = *(const f16x8*)(bw + kk * 16);
-            wf[1] = *(const f16x8*)(bw + 32 * LDSS + kk * 16);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-        }
-        if (ks + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-    igemm_epilogue<2, 2>(a, acc, m0 + wm * 64, n0 + wn * 64, lane, smem + wave * EPI_SLAB_BYTES);
+    // the wave must not retire with an LDS DMA (the last tile's dummy prefetch) in flight: the LDS allocation could be
+    // handed to another workgroup while the DMA still writes into it
+    wait_vmcnt<0>();
+    TRACE_FLUSH();
 }
 
 extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (!a || !a->x || !a->w || !a->out) return MOFA_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->Cin <= 0) return MOFA_EINVAL;
-    if (a->Cin % BK != 0 || a->N % 4 != 0) return MOFA_EINVAL;
+    if (a->Cin % 64 != 0 || a->N % 4 != 0) return MOFA_EINVAL;
     if (a->mode < 0 || a->mode > 2) return MOFA_EINVAL;
     if (a->mode == MOFA_MODE_CONV3X3) {
         if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return MOFA_EINVAL;
@@ -462,58 +536,59 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (a->ldx % 8 != 0 || a->ldo % 4 != 0) return MOFA_EINVAL;
     if ((a->r1 && a->ldr1 % 4 != 0) || (a->r2 && a->ldr2 % 4 != 0)) return MOFA_EINVAL;
 
-    // kernel configurations of the LDS-DMA ring: {tile, K per stage, stages}
+    // two tile configurations x nine epilogue kinds (bit 0 r1, bit 1 r2, bit 2 row vector; 8 = GEGLU pair)
     typedef void (*kern_t)(const mofa_igemm_args, const int, const int);
-    struct Cfg { kern_t k; int tm, tn, threads, lds; };
-    static const Cfg cfgs[] = {
-        {igemm_f16_kernel<2, 2, 2, 2, 32, 4>, 128, 128, 256, 4 * 256 * 64},    // 0: 128^2, 64-B rows, 3 tiles in flight
-        {igemm_f16_kernel<2, 4, 4, 2, 32, 4>, 256, 256, 512, 4 * 512 * 64},    // 1: 256^2, 64-B rows, 3 tiles in flight
-        {igemm_f16_kernel<2, 2, 2, 2, 64, 2>, 128, 128, 256, 2 * 256 * 128},   // 2: 128^2, 128-B rows, 1 tile in flight
-        {igemm_f16_kernel<2, 4, 4, 2, 64, 2>, 256, 256, 512, 2 * 512 * 128},   // 3: 256^2, 128-B rows, 1 tile in flight
-        {igemm_f16_kernel<2, 2, 2, 2, 64, 3>, 128, 128, 256, 3 * 256 * 128},   // 4: 128^2, 128-B rows, 2 tiles in flight
-        {igemm_f16_kernel<4, 2, 2, 2, 64, 3>, 256, 128, 512, 3 * 384 * 128},   // 5: 256x128, 128-B rows, 2 tiles in flight
-        {igemm_f16_kernel<2, 4, 2, 2, 64, 3>, 128, 256, 512, 3 * 384 * 128},   // 6: 128x256, 128-B rows, 2 tiles in flight
+    struct Cfg { kern_t k[9]; int tm, tn, threads, lds, wg_per_cu; };
+#define IGEMM_KINDS(WM, WN, MI)                                                                                        \
+    {igemm_f16_kernel<WM, WN, MI, 0>, igemm_f16_kernel<WM, WN, MI, 1>, igemm_f16_kernel<WM, WN, MI, 2>,                \
+     igemm_f16_kernel<WM, WN, MI, 3>, igemm_f16_kernel<WM, WN, MI, 4>, igemm_f16_kernel<WM, WN, MI, 5>,                \
+     igemm_f16_kernel<WM, WN, MI, 6>, igemm_f16_kernel<WM, WN, MI, 7>, igemm_f16_kernel<WM, WN, MI, 8>}
+    static const Cfg cfgs[2] = {
+        {IGEMM_KINDS(2, 2, 2), 128, 128, 256, 2 * 256 * 128, 2},   // 128^2 tile, 2 workgroups per CU
+        {IGEMM_KINDS(2, 4, 4), 256, 256, 512, 2 * 512 * 128, 1},   // 256^2 tile, 1 workgroup per CU
     };
-    static int variant = -1;   // -2 = register-staged kernel, -1 unset, otherwise forced cfg (or 100 = auto)
+    static int variant = -1;   // -1 unset, 0 / 1 forced configuration (MOFA_IGEMM_CFG=2 / 3), 100 = auto
+    static int n_cu = 256;
     if (variant == -1) {
-        const char* e = getenv("MOFA_IGEMM_REGSTAGE");
         const char* e2 = getenv("MOFA_IGEMM_CFG");
-        variant = (e && e[0] == '1') ? -2 : (e2 ? atoi(e2) : 100);
+        const int v = e2 ? atoi(e2) : 100;
         for (const Cfg& c : cfgs)
-            if (hipFuncSetAttribute((const void*)c.k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess) {
-                variant = -1;
-                return MOFA_ELAUNCH;
-            }
-        if (hipFuncSetAttribute((const void*)igemm_regstage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                REGSTAGE_LDS_BYTES) != hipSuccess) {
-            variant = -1;
-            return MOFA_ELAUNCH;
-        }
+            for (kern_t k : c.k)
+                if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess)
+                    return MOFA_ELAUNCH;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            n_cu = cus;
+        const char* e3 = getenv("MOFA_IGEMM_STAGGER");
+        const int stg = e3 ? atoi(e3) : 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_stagger), &stg, sizeof(int)) != hipSuccess) return MOFA_ELAUNCH;
+        variant = (v == 2) ? 0 : (v == 3 ? 1 : 100);
     }
-    hipStream_t st = (hipStream_t)stream;
-    if (variant == -2) {
-        const int tilesM = cdiv(a->M, BM), tilesN = cdiv(a->N, BN);
-        hipLaunchKernelGGL(igemm_regstage_kernel, dim3(tilesM * tilesN), dim3(256), REGSTAGE_LDS_BYTES, st, *a, tilesN,
-                           tilesM * tilesN);
-    } else {
-        int ci = variant;
-        if (variant == 100) {
-            // 256x256 tiles halve the global->LDS fill traffic per flop; use them when the column count fills them
-            // (<= 1/8 padding waste) and the grid still covers the chip
-            // measured on MI355X (profiles/r01_igemm_config_sweep.md): 128-byte LDS rows (whole cache lines per DMA
-            // row) beat the deeper 64-byte-row ring everywhere; 256x256 tiles win when N is wide relative to K
-            // (GEGLU / QKV projections), 128x128 (2 workgroups per CU) otherwise.
-            const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
-            const long long Ktot = (long long)taps * a->Cin;
-            const int t256m = cdiv(a->M, 256), t256n = cdiv(a->N, 256);
-            const bool big = (long long)t256n * 256 * 8 <= (long long)a->N * 9 && t256m * t256n >= 256 &&
-                             (long long)a->N >= 2 * Ktot;
-            ci = big ? 3 : 2;
-        }
-        const Cfg& c = cfgs[ci];
-        const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
-        hipLaunchKernelGGL(c.k, dim3(tilesM * tilesN), dim3(c.threads), c.lds, st, *a, tilesN, tilesM * tilesN);
+    const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
+    const long long Ktot = (long long)taps * a->Cin;
+    int ci = variant;
+    if (variant == 100) {
+        // 256x256 tiles halve the global->LDS fill traffic per flop; use them when the column count fills them
+        // (<= 1/8 padding waste), the grid still covers the chip and N is wide relative to K (GEGLU / QKV projections);
+        // 128x128 (2 workgroups per CU) otherwise (profiles/r01_igemm_config_sweep.md)
+        const int t256m = cdiv(a->M, 256), t256n = cdiv(a->N, 256);
+        const bool big = (long long)t256n * 256 * 8 <= (long long)a->N * 9 && t256m * t256n >= 256 &&
+                         (long long)a->N >= 2 * Ktot;
+        ci = big ? 1 : 0;
     }
+    const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
+    if (variant == 100 && kind != 0 && kind != 8) ci = 0;      // the 256x256 tile has no registers for residual loads
+    const Cfg& c = cfgs[ci];
+    const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
+    const long long nt = (long long)tilesM * tilesN;
+    if (nt > 0x7fffffffLL) return MOFA_EINVAL;
+    static int persist = -1;
+    if (persist < 0) { const char* e = getenv("MOFA_IGEMM_PERSIST"); persist = e ? atoi(e) : 1; }
+    const int slots = persist > 0 ? n_cu * c.wg_per_cu * persist : 0x7ffffff8;   // resident workgroups (a multiple of 8 on gfx950)
+    int grid = (int)(nt < slots ? ((nt + 7) / 8) * 8 : (slots / 8) * 8);
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL(c.k[kind], dim3(grid), dim3(c.threads), c.lds, (hipStream_t)stream, *a, tilesN, (int)nt);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

@@ -397,3 +397,42 @@ def test_attn_temporal_sharded_queries(ops):
     kv = d[:, Cc:].contiguous()
     part = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, T, HW, heads, Tq=Tq)
     assert torch.equal(part, full[f0 * HW:(f0 + Tq) * HW])
+
+
+@pytest.mark.parametrize("N,kinds", [(64, ("r1",)), (64, ("r1", "rv")), (64, ("bias", "r1", "r2", "rv")), (256, ("r1",)),
+                                     (256, ("bias",)), (128, ("bias", "r1"))])
+def test_igemm_repeat_launches_bit_identical(ops, N, kinds):
+    """Regression for an intermittent epilogue fault (dropped residual term in lanes 48..63 of the 128x128-tile kernel,
+    see the comment on the scale factors in csrc/igemm.hip): repeated launches of one conv + epilogue must agree bit
+    for bit, and with a torch fp32 reference within fp16 rounding."""
+    torch.manual_seed(5)
+    n, H, W, C = 4, 128, 128, 64
+    x = torch.randn(n * H * W, C, device=DEV).half()
+    w = (torch.randn(N, 9 * C, device=DEV) * 0.05).half()
+    kw = {}
+    if "bias" in kinds:
+        kw["bias"] = torch.randn(N, device=DEV)
+    if "r1" in kinds:
+        kw["r1"] = torch.randn(n * H * W, N, device=DEV).half()
+    if "r2" in kinds:
+        kw["r2"] = torch.randn(n * H * W, N, device=DEV).half()
+        kw["s2"] = 0.5
+    if "rv" in kinds:
+        kw["rowvec"] = torch.randn(n, N, device=DEV)
+        kw["rv"] = (H * W, 1, 1, n)
+    g = ops.conv3x3_geom(H, W)
+    outs = [ops.igemm(x, w, geom=g, **kw).clone() for _ in range(6)]
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    ref = torch.nn.functional.conv2d(x.view(n, H, W, C).permute(0, 3, 1, 2).float(),
+                                     w.view(N, 3, 3, C).permute(0, 3, 1, 2).float(), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, N)
+    if "bias" in kinds:
+        ref = ref + kw["bias"]
+    if "rv" in kinds:
+        ref = ref + kw["rowvec"].repeat_interleave(H * W, 0)
+    if "r1" in kinds:
+        ref = ref + kw["r1"].float()
+    if "r2" in kinds:
+        ref = ref + 0.5 * kw["r2"].float()
+    _close(outs[0], ref, tol=4e-3, what="conv + epilogue vs torch fp32")
