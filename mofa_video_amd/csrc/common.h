@@ -18,18 +18,26 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     } while (0)
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// exact (erf) GELU as diffusers' GEGLU uses it.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the
-// fp16 rounding of the result): ~12 VALU ops instead of libm erff's ~40 -- the GEGLU epilogue evaluates it
-// 4*C times per token.
+// erf GELU as diffusers' GEGLU uses it: gelu(x) = 0.5 * (x + |x| * erf(|x| / sqrt2)).  erf(z) on [0, 3] is an odd
+// minimax polynomial z * P(z^2) of degree 17 (|error| <= 2.9e-5, fitted in tools/fit_erf.py) and 1 beyond: 14 full-rate
+// VALU operations that hipcc packs two elements at a time (v_pk_fma_f32), no transcendental.  The previous
+// Abramowitz-Stegun 7.1.26 form needed v_exp_f32 + v_rcp_f32 (quarter rate): the GEGLU epilogue evaluates this
+// 4 * C times per token and was VALU-bound on it.  |gelu error| <= 6.1e-5 absolute (fp16 rounding of an O(1) result:
+// 2.4e-4).
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-z * z);      // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
+    const float ax = fabsf(x);
+    const float z = fminf(ax * 0.70710678118654752f, 3.0f);
+    const float u = z * z;
+    float p = 4.074214033e-08f;
+    p = fmaf(p, u, -1.944823907e-06f);
+    p = fmaf(p, u, 4.106053893e-05f);
+    p = fmaf(p, u, -5.110369530e-04f);
+    p = fmaf(p, u, 4.235427827e-03f);
+    p = fmaf(p, u, -2.510286123e-02f);
+    p = fmaf(p, u, 1.110793352e-01f);
+    p = fmaf(p, u, -3.753148615e-01f);
+    p = fmaf(p, u, 1.128268480e+00f);
+    return 0.5f * fmaf(ax, z * p, x);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -97,7 +97,9 @@ struct TileWalk {
     }
 };
 
-__device__ int g_igemm_stagger = 0;   // start delay of the upper half of the grid, units of 512 clocks
+#ifndef IGEMM_INTERLEAVE
+#define IGEMM_INTERLEAVE 1   // 1: spread the DMA issue of a K step over its four MFMA groups (compile with -DIGEMM_INTERLEAVE=0 for A/B)
+#endif
 
 #define EPI_R1 1
 #define EPI_R2 2
@@ -354,11 +356,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
     TileWalk walk;
     walk.init(ntiles);
     if (walk.local >= walk.count) return;                          // whole workgroup idle
-    // co-resident workgroups (second half of each XCD's share of the grid) start half a K step late: two workgroups
-    // of one CU then alternate DMA wait and MFMA phases instead of colliding in both
-    if (g_igemm_stagger > 0 && (int)(blockIdx.x >> 3) >= (int)(gridDim.x >> 4))
-        for (int i = 0; i < g_igemm_stagger; ++i) __builtin_amdgcn_s_sleep(8);
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -461,6 +458,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
             }
         };
+        // refill of stage `nxt` spread over the four MFMA groups of stage `cur`: 2 DMA instructions, then 6 ds_reads and
+        // 4 (8) MFMAs, four times -- the TA sees a steady trickle instead of a burst and the first MFMA does not wait
+        // for the address arithmetic of all eight DMA instructions
+        auto compute_and_issue = [&](int cur, int nxt) {
+            if (ikc == 0) {
+#pragma unroll
+                for (int q = 0; q < XI; ++q) xs[q] = x_src(a, geo[q], itap);
+            }
+            const char* sb = smem + cur * STB;
+            char* nb = smem + nxt * STB;
+            constexpr int OPK = (XI + WI) / (BKS / 16);      // DMA instructions per MFMA group
+            static_assert(OPK * (BKS / 16) == XI + WI, "DMA instructions must divide over the MFMA groups");
+#pragma unroll
+            for (int kk = 0; kk < BKS / 16; ++kk) {
+#pragma unroll
+                for (int o = kk * OPK; o < (kk + 1) * OPK; ++o) {
+                    if (o < XI) {
+                        const f16* sp = xs[o] ? xs[o] + ikc * BKS + xoff[o] : (const f16*)g_zero_page;
+                        glds16(sp, nb + (wave * XI + o) * 1024);
+                    } else {
+                        glds16(wsrc[o - XI] + (size_t)ksw * BKS, nb + SXB + (wave * WI + (o - XI)) * 1024);
+                    }
+                }
+                const int slot = ((kk * 2 + lh) ^ fsw) * 16;
+                f16x8 xf[MI], wf[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8*)(sb + xrow + i * 32 * RB + slot);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) wf[j] = *(const f16x8*)(sb + wrow + j * 32 * RB + slot);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+            }
+            ++ksw;
+            if (++ikc == kpt) { ikc = 0; ++itap; }
+        };
         // K steps 0 .. nk-2: wait for the only DMA in flight (at step 0 the previous epilogue's stores may stay
         // outstanding), one barrier (all waves' parts landed; the other stage is free), refill, multiply
         for (int ks = 0; ks < nk - 1; ++ks) {
@@ -468,8 +503,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
             __builtin_amdgcn_s_barrier();
             if (ks == 0) TRACE_ADD(0);               // bucket 0: waiting for a tile's first stage
             const int cur = (par + ks) & 1;
+#if IGEMM_INTERLEAVE
+            compute_and_issue(cur, cur ^ 1);
+#else
             issue(cur ^ 1);
             compute(cur);
+#endif
         }
         // last K step (peeled: the set-up of the next tile stays out of the steady-state loop)
         const int last = (par + nk - 1) & 1;
@@ -560,9 +599,6 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             n_cu = cus;
-        const char* e3 = getenv("MOFA_IGEMM_STAGGER");
-        const int stg = e3 ? atoi(e3) : 0;
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_igemm_stagger), &stg, sizeof(int)) != hipSuccess) return MOFA_ELAUNCH;
         variant = (v == 2) ? 0 : (v == 3 ? 1 : 100);
     }
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
