@@ -238,8 +238,8 @@ def main():
         at = summ.get("attn_spatial_kernel")
         traffic = None       # HBM bytes per launch from the committed PMC passes (not collectable live)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01b_igemm_traffic.json")))
-            traffic = dict(hbm_bytes_per_launch=round(tj["hbm_bytes_per_launch"]), source="profiles/r01b_igemm_traffic.json "
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01c_igemm_traffic.json")))
+            traffic = dict(hbm_bytes_per_launch=round(tj["hbm_bytes_per_launch"]), source="profiles/r01c_igemm_traffic.json "
                            "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)")
         except Exception:  # noqa: BLE001
             pass
