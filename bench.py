@@ -221,10 +221,9 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
-    if isinstance(frames, list):                            # shard mode: the VAE chunks this rank decoded
-        finite = all(bool(torch.isfinite(f).all().item()) for _, f in frames)
-    else:
-        finite = bool(torch.isfinite(frames).all().item())
+    # "pt" output = the reference's tensor2vid result: a list with one [T,3,H,W] tensor in [0,1] per batch element
+    # (single rank), or the list of (first_frame, [n,3,H,W]) VAE chunks this rank decoded (shard mode)
+    finite = all(bool(torch.isfinite(f[1] if isinstance(f, tuple) else f).all().item()) for f in frames)
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

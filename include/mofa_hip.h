@@ -195,6 +195,22 @@ int mofa_prepare_model_input(const float* latents, const float* image_latents, v
 int mofa_cfg_euler_step(float* latents, const void* noise_pred, int T, int HW, int ldn,
                         float sigma, float sigma_next, float gmin, float gmax, mofa_stream_t stream);
 
+
+/* ---- output stage (the step after the path) -------------------------------------------------------------
+ * Replaces tensor2vid -> VaeImageProcessor.postprocess (Traj/pipeline/pipeline.py:57-69, :518): decoded fp32 frames
+ * [nframes][3][H][W] -> (x/2+0.5).clamp(0,1) as fp32 NCHW ("pt"), fp32 NHWC ("np") or uint8 NHWC ("pil":
+ * round-half-even(x*255)). */
+#define MOFA_FRAMES_PT 0
+#define MOFA_FRAMES_NP 1
+#define MOFA_FRAMES_U8 2
+int mofa_frames_postprocess_f32(const float* frames_nchw, void* out, int nframes, int H, int W, int mode,
+                                mofa_stream_t stream);
+/* Middlebury colour coding of one flow field, fp32 [H][W][2] -> uint8 [H][W][3]; replaces flow_to_image
+ * (Traj/utils/flow_viz.py:241-277 with compute_color :196-238).  workspace: mofa_flow_to_image_ws_bytes(H, W). */
+int64_t mofa_flow_to_image_ws_bytes(int H, int W);
+int mofa_flow_to_image_u8(const float* flow_hw2, unsigned char* out_hw3, int H, int W, void* workspace,
+                          mofa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,8 +70,11 @@ PROTOTYPES = {
     "mofa_flow_downscale_f32": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_prepare_model_input": [_P, _P, _P, _I, _I, _I, _F, _P],
     "mofa_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+    "mofa_frames_postprocess_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_flow_to_image_ws_bytes": [_I, _I],
+    "mofa_flow_to_image_u8": [_P, _P, _I, _I, _P, _P],
 }
-_RESTYPE = {"mofa_softsplat_ws_bytes": C.c_int64}
+_RESTYPE = {"mofa_softsplat_ws_bytes": C.c_int64, "mofa_flow_to_image_ws_bytes": C.c_int64}
 
 _lib = None
 

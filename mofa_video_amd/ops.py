@@ -439,3 +439,33 @@ def cfg_euler_step_(latents, noise_pred, sigma, sigma_next, gmin, gmax):
     L.check(lib.mofa_cfg_euler_step(L.ptr(latents), L.ptr(noise_pred), T, h * w, _ld(noise_pred), float(sigma),
                                     float(sigma_next), float(gmin), float(gmax), L.stream_ptr()), "mofa_cfg_euler_step")
     return latents
+
+
+# ---- output stage ---------------------------------------------------------------------------
+def frames_postprocess(frames, mode):
+    """decoded fp32 frames [n,3,H,W] -> mode 0: fp32 [n,3,H,W] in [0,1]; 1: fp32 [n,H,W,3]; 2: uint8 [n,H,W,3]."""
+    lib = L.load()
+    _chk(frames, F32)
+    n, c, H, W = frames.shape
+    assert c == 3
+    frames = frames.contiguous()
+    if mode == 0:
+        out = torch.empty_like(frames)
+    else:
+        out = torch.empty((n, H, W, 3), dtype=F32 if mode == 1 else torch.uint8, device=frames.device)
+    L.check(lib.mofa_frames_postprocess_f32(L.ptr(frames), L.ptr(out), n, H, W, mode, L.stream_ptr()),
+            "mofa_frames_postprocess_f32")
+    return out
+
+
+def flow_to_image(flow_hw2):
+    """fp32 flow [H,W,2] -> uint8 Middlebury colour image [H,W,3]."""
+    lib = L.load()
+    _chk(flow_hw2, F32)
+    H, W, two = flow_hw2.shape
+    assert two == 2
+    flow_hw2 = flow_hw2.contiguous()
+    ws = torch.empty((lib.mofa_flow_to_image_ws_bytes(H, W),), dtype=torch.uint8, device=flow_hw2.device)
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=flow_hw2.device)
+    L.check(lib.mofa_flow_to_image_u8(L.ptr(flow_hw2), L.ptr(out), H, W, L.ptr(ws), L.stream_ptr()), "mofa_flow_to_image_u8")
+    return out

@@ -27,6 +27,7 @@ import torch
 
 from . import ops
 from .blocks import Ctx
+from .output import tensor2vid
 from .vae import decode_latents
 
 
@@ -169,6 +170,8 @@ class FlowControlNetPipeline:
             frames = latents_out
         elif lay is None or lay.world == 1:
             frames = decode_latents(self.vae, latents_out, T, decode_chunk_size)       # fp32 [1,3,T,H,W]
+            if output_type != "raw":                                                   # pipeline.py:518
+                frames = tensor2vid(frames, None, output_type=output_type)
         else:
             # VAE chunks are independent (pipeline.py:204-213): dealt round-robin to all ranks; the result is the list
             # of (first_frame, fp32 [n,3,H,W]) chunks this rank decoded
@@ -177,7 +180,10 @@ class FlowControlNetPipeline:
             for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
                 if ci % lay.world == lay.rank:
                     z = latents_out[0, s0:s0 + decode_chunk_size]
-                    frames.append((s0, self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)))
+                    fr = self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)           # fp32 [n,3,H,W]
+                    if output_type != "raw":
+                        fr = tensor2vid(fr.permute(1, 0, 2, 3).unsqueeze(0), None, output_type=output_type)[0]
+                    frames.append((s0, fr))
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
@@ -244,6 +250,8 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
             ops.cfg_euler_step_(lat, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
         latents_out = lat.reshape(1, T, 4, h, w)
         frames = latents_out if output_type == "latent" else decode_latents(self.vae, latents_out, T, decode_chunk_size)
+        if output_type not in ("latent", "raw"):
+            frames = tensor2vid(frames, None, output_type=output_type)
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
@@ -329,6 +337,8 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
                     ops.axpby_f32_(value[f].reshape(-1), lat[f].reshape(-1), 1.0 / count[f], 0.0)
         latents_out = lat.reshape(1, N, 4, h, w)
         frames = latents_out if output_type == "latent" else decode_latents(self.vae, latents_out, N, decode_chunk_size)
+        if output_type not in ("latent", "raw"):
+            frames = tensor2vid(frames, None, output_type=output_type)
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)

@@ -79,7 +79,7 @@ def test_sharded_latents_equal_single_rank(setup, world):
 
 def test_sharded_decode_covers_all_chunks(setup):
     run = setup
-    ref = run(None, "pt")                                           # [1,3,T,H,W]
+    ref = run(None, "pt")[0]                                        # tensor2vid: one [T,3,H,W] tensor per batch element
     outs = _run_virtual_ranks(run, 4, "pt")
     seen = {}
     for r, chunks in enumerate(outs):
@@ -87,6 +87,6 @@ def test_sharded_decode_covers_all_chunks(setup):
             seen[s0] = fr
     assert sorted(seen) == [0, 2]
     got = torch.cat([seen[k] for k in sorted(seen)], 0)              # [T,3,H,W]
-    e = rel_l2(got, ref[0].permute(1, 0, 2, 3))
+    e = rel_l2(got, ref)
     print(f"sharded decode rel-L2 {e:.3e}")
     assert e < 3e-3, e
