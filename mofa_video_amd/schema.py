@@ -211,12 +211,70 @@ def vae_decoder_schema(block_out_channels=(128, 256, 512, 512), layers_per_block
     return d
 
 
-def synthetic_state_dict(schema, seed=0, device="cpu", dtype=torch.float16):
+def _bn(d, p, c):
+    d[p + ".weight"] = (c,)
+    d[p + ".bias"] = (c,)
+    d[p + ".running_mean"] = (c,)
+    d[p + ".running_var"] = (c,)
+    d[p + ".num_batches_tracked"] = ()
+
+
+def cmp_schema():
+    """CMP module at the inference configuration (Traj/models/cmp/experiments/semiauto_annot/
+    resnet50_vip+mpii_liteflow/config.yaml): dilated ResNet-50 (resnet.py:49-166), shallownet8x (shallownet.py:4-41),
+    MotionDecoderSkipLayer (decoder.py:96-188); keys as ``CMP(params).state_dict()`` (modules/cmp.py:6-25)."""
+    d = {}
+    e = "image_encoder"
+    d[f"{e}.conv1.weight"] = (64, 3, 7, 7)
+    _bn(d, f"{e}.bn1", 64)
+    inplanes = 64
+    for li, (planes, blocks) in enumerate(((64, 3), (128, 4), (256, 6), (512, 3)), start=1):
+        for b in range(blocks):
+            q = f"{e}.layer{li}.{b}"
+            d[f"{q}.conv1.weight"] = (planes, inplanes, 1, 1)
+            _bn(d, f"{q}.bn1", planes)
+            d[f"{q}.conv2.weight"] = (planes, planes, 3, 3)
+            _bn(d, f"{q}.bn2", planes)
+            d[f"{q}.conv3.weight"] = (planes * 4, planes, 1, 1)
+            _bn(d, f"{q}.bn3", planes * 4)
+            if b == 0:
+                d[f"{q}.downsample.0.weight"] = (planes * 4, inplanes, 1, 1)
+                _bn(d, f"{q}.downsample.1", planes * 4)
+            inplanes = planes * 4
+    _conv(d, f"{e}.conv5", 256, 2048, 1, 1)
+    f = "flow_encoder.features"
+    _conv(d, f"{f}.0", 16, 4, 5, 5)
+    _bn(d, f"{f}.1", 16)
+    _conv(d, f"{f}.4", 16, 16, 3, 3)
+    _bn(d, f"{f}.5", 16)
+    g = "flow_decoder"
+    for name, first in (("decoder1", 0), ("decoder2", 1), ("decoder4", 1), ("decoder8", 1)):
+        cin = 256 + 16
+        for j in range(3):
+            _conv(d, f"{g}.{name}.{first + 3 * j}", 128, cin, 3, 3)
+            _bn(d, f"{g}.{name}.{first + 3 * j + 1}", 128)
+            cin = 128
+    for name, cin, cout in (("fusion8", 512, 256), ("skipconv4", 256, 128), ("fusion4", 384, 128), ("skipconv2", 64, 32),
+                            ("fusion2", 160, 64)):
+        _conv(d, f"{g}.{name}.0", cout, cin, 3, 3)
+        _bn(d, f"{g}.{name}.1", cout)
+    _conv(d, f"{g}.head", 198, 64, 1, 1)
+    return d
+
+
+def synthetic_state_dict(schema, seed=0, device="cpu", dtype=torch.float16, gain=1.0):
     """Seeded random weights in the reference layout (default-init-like scales; zero-initialised reference
-    layers are random too, otherwise the adapter would contribute nothing -- SURVEY 8c)."""
+    layers are random too, otherwise the adapter would contribute nothing -- SURVEY 8c).  ``gain`` scales the
+    matrix / convolution weights (2.0 keeps the ReLU + BatchNorm-eval CMP encoder's activations O(1))."""
     g = torch.Generator(device=device).manual_seed(seed)
     sd = {}
     for k, shape in schema.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros(shape, dtype=torch.long, device=device)
+            continue
+        if k.endswith("running_var"):
+            sd[k] = (0.75 + 0.5 * torch.rand(shape, generator=g, device=device)).to(dtype)
+            continue
         if k.endswith("mix_factor"):
             t = torch.full(shape, 0.5, device=device) + 0.3 * torch.randn(shape, generator=g, device=device)
         elif len(shape) == 1:
@@ -228,6 +286,6 @@ def synthetic_state_dict(schema, seed=0, device="cpu", dtype=torch.float16):
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
-            t = (torch.rand(shape, generator=g, device=device) * 2 - 1) / math.sqrt(fan_in)
+            t = (torch.rand(shape, generator=g, device=device) * 2 - 1) * (gain / math.sqrt(fan_in))
         sd[k] = t.to(dtype)
     return sd
