@@ -48,7 +48,7 @@ int mofa_version(void);
  * models/unet_spatio_temporal_condition_controlnet.py:169-232, models/controlnet_sdv.py:259-309)
  * and the adapter's own convs (models/svdxt_featureflow_forward_controlnet_s2d_fixcmp_norefine.py:66-155).
  * ---------------------------------------------------------------------------------------- */
-enum { MOFA_MODE_PLAIN = 0, MOFA_MODE_CONV3X3 = 1, MOFA_MODE_CONVT3 = 2 };   /* CONV3X3 = k x k conv, k = ksize (3 or 7) */
+enum { MOFA_MODE_PLAIN = 0, MOFA_MODE_CONV3X3 = 1, MOFA_MODE_CONVT3 = 2 };   /* CONV3X3 = k x k conv, k = ksize (1, 3, 5 or 7) */
 enum { MOFA_ACT_NONE = 0, MOFA_ACT_SILU = 1, MOFA_ACT_GEGLU_PAIR = 2, MOFA_ACT_RELU = 3 };
 
 typedef struct mofa_igemm_args {
@@ -62,8 +62,8 @@ typedef struct mofa_igemm_args {
     int32_t M, N, Cin;  /* Cin % 64 == 0, N % 4 == 0                                         */
     int32_t ldx, ldo, ldr1, ldr2;
     int32_t mode;       /* MOFA_MODE_*                                                       */
-    /* MOFA_MODE_CONV3X3: rows are (img, oy, ox); k x k taps (ksize 3 or 7; 0 means 3), pad k/2; */
-    /* stride 1|2; up = 1|2 (nearest-neighbour upsampling of the input before the conv)      */
+    /* MOFA_MODE_CONV3X3: rows are (img, oy, ox); k x k taps (ksize 1, 3, 5 or 7; 0 means 3), dilation dil,  */
+    /* pad dil*(k/2); stride 1|2; up = 1|2 (nearest-neighbour upsampling of the input before the conv)      */
     int32_t Hin, Win, Hout, Wout, stride, up, ksize;
     /* MOFA_MODE_CONVT3: rows are (frame, pixel); frames grouped in clips of T; T = 0: no     */
     /* clipping at clip ends (the caller placed halo frames before/after the rows)           */
@@ -71,6 +71,8 @@ typedef struct mofa_igemm_args {
     int32_t rv_div, rv_mul, rv_mod_in, rv_mod_out;
     int32_t act;        /* MOFA_ACT_*                                                        */
     float s_acc, s1, s2;
+    int32_t dil;        /* MOFA_MODE_CONV3X3: tap dilation (0 means 1); the CMP encoder's de-strided ResNet stages use 2 and 4
+                         * (Traj/models/cmp/models/backbone/resnet.py:118-129).  Occupies the former tail padding: sizeof = 160 */
 } mofa_igemm_args;
 
 int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
@@ -210,6 +212,22 @@ int mofa_frames_postprocess_f32(const float* frames_nchw, void* out, int nframes
 int64_t mofa_flow_to_image_ws_bytes(int H, int W);
 int mofa_flow_to_image_u8(const float* flow_hw2, unsigned char* out_hw3, int H, int W, void* workspace,
                           mofa_stream_t stream);
+
+/* ---- CMP sparse-to-dense motion encoder, non-convolution pieces (the step before the path) -----------------
+ * Token-major fp16 maps [nimg*H*W][ld].  pool2d: nn.MaxPool2d (mode 0, padding ignored) / nn.AvgPool2d (mode 1)
+ * (Traj/models/cmp/models/backbone/resnet.py:108, modules/shallownet.py:16-21, modules/decoder.py:115-139). */
+int mofa_pool2d_f16(const void* x, void* out, int nimg, int Hin, int Win, int C, int ldx, int ldo, int k, int stride, int pad,
+                    int mode, mofa_stream_t stream);
+/* F.interpolate(mode="bilinear", align_corners=True): token-major fp16 maps (modules/decoder.py:192-211) and fp32
+ * planes [nplanes][H][W] (svdxt_..._norefine.py:58-60). */
+int mofa_resize_bilinear_ac_f16(const void* x, void* out, int nimg, int Hin, int Win, int Hout, int Wout, int C, int ldx, int ldo,
+                                mofa_stream_t stream);
+int mofa_resize_bilinear_ac_f32(const float* x, float* out, int nplanes, int Hin, int Win, int Hout, int Wout,
+                                mofa_stream_t stream);
+/* Fuser.convert_flow (cmp/utils/visualize_utils.py:6-19): logits fp16 [nimg*HW][ld], bins [0,nbins) x, [nbins,2nbins) y
+ * -> fp32 flow [nimg][2][HW] = per-axis softmax expectation over the bin centres (b + 1/2) * 2*fmax/nbins - fmax. */
+int mofa_flow_expectation_f16(const void* logits, float* flow_nchw, int nimg, int HW, int ld, int nbins, float fmax,
+                              mofa_stream_t stream);
 
 #ifdef __cplusplus
 }

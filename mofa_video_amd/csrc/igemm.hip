@@ -68,9 +68,10 @@ __device__ __forceinline__ const f16* x_src(const mofa_igemm_args& a, const RowG
         return x + (size_t)g.m * a.ldx;
     } else if (a.mode == MOFA_MODE_CONV3X3) {
         const int ks = a.ksize > 0 ? a.ksize : 3;
+        const int dil = a.dil > 0 ? a.dil : 1;
         const int ky = tap / ks, kx = tap - ky * ks;
-        const int vy = g.oy * a.stride + ky - (ks >> 1);
-        const int vx = g.ox * a.stride + kx - (ks >> 1);
+        const int vy = g.oy * a.stride + (ky - (ks >> 1)) * dil;
+        const int vx = g.ox * a.stride + (kx - (ks >> 1)) * dil;
         if (vy < 0 || vx < 0 || vy >= a.Hin * a.up || vx >= a.Win * a.up) return nullptr;
         const int iy = (a.up == 2) ? (vy >> 1) : vy;
         const int ix = (a.up == 2) ? (vx >> 1) : vx;
@@ -565,7 +566,8 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (a->mode == MOFA_MODE_CONV3X3) {
         if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return MOFA_EINVAL;
         if ((a->stride != 1 && a->stride != 2) || (a->up != 1 && a->up != 2)) return MOFA_EINVAL;
-        if (a->ksize != 0 && a->ksize != 3 && a->ksize != 7) return MOFA_EINVAL;
+        if (a->ksize != 0 && a->ksize != 1 && a->ksize != 3 && a->ksize != 5 && a->ksize != 7) return MOFA_EINVAL;
+        if (a->dil < 0 || (a->dil > 1 && a->up != 1)) return MOFA_EINVAL;
         if (a->M % (a->Hout * a->Wout) != 0) return MOFA_EINVAL;
     }
     if (a->mode == MOFA_MODE_CONVT3 && (a->T < 0 || a->HW <= 0 || (a->T > 0 && a->M % (a->T * a->HW) != 0)))

@@ -30,6 +30,7 @@ class IgemmArgs(C.Structure):
         ("rv_div", C.c_int32), ("rv_mul", C.c_int32), ("rv_mod_in", C.c_int32), ("rv_mod_out", C.c_int32),
         ("act", C.c_int32),
         ("s_acc", C.c_float), ("s1", C.c_float), ("s2", C.c_float),
+        ("dil", C.c_int32),
     ]
 
 
@@ -70,6 +71,10 @@ PROTOTYPES = {
     "mofa_flow_downscale_f32": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_prepare_model_input": [_P, _P, _P, _I, _I, _I, _F, _P],
     "mofa_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+    "mofa_pool2d_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mofa_resize_bilinear_ac_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "mofa_resize_bilinear_ac_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "mofa_flow_expectation_f16": [_P, _P, _I, _I, _I, _I, _F, _P],
     "mofa_frames_postprocess_f32": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_flow_to_image_ws_bytes": [_I, _I],
     "mofa_flow_to_image_u8": [_P, _P, _I, _I, _P, _P],

@@ -74,22 +74,22 @@ def _chk(t, dtype):
 
 class ConvGeom:
     """Geometry of an implicit-GEMM launch."""
-    __slots__ = ("mode", "Hin", "Win", "Hout", "Wout", "stride", "up", "T", "HW", "ksize")
+    __slots__ = ("mode", "Hin", "Win", "Hout", "Wout", "stride", "up", "T", "HW", "ksize", "dil")
 
-    def __init__(self, mode=L.MODE_PLAIN, Hin=0, Win=0, Hout=0, Wout=0, stride=1, up=1, T=0, HW=0, ksize=3):
+    def __init__(self, mode=L.MODE_PLAIN, Hin=0, Win=0, Hout=0, Wout=0, stride=1, up=1, T=0, HW=0, ksize=3, dil=1):
         self.mode, self.Hin, self.Win, self.Hout, self.Wout = mode, Hin, Win, Hout, Wout
-        self.stride, self.up, self.T, self.HW, self.ksize = stride, up, T, HW, ksize
+        self.stride, self.up, self.T, self.HW, self.ksize, self.dil = stride, up, T, HW, ksize, dil
 
 
 PLAIN = ConvGeom()
 
 
-def conv3x3_geom(H, W, stride=1, up=1, ksize=3):
-    """k x k convolution with padding k//2 (k = 3 or 7)"""
+def conv3x3_geom(H, W, stride=1, up=1, ksize=3, dil=1):
+    """k x k convolution (k = 1, 3, 5, 7) with dilation dil and padding dil * (k // 2)"""
     Hv, Wv = H * up, W * up
     Ho = (Hv - 1) // stride + 1
     Wo = (Wv - 1) // stride + 1
-    return ConvGeom(L.MODE_CONV3X3, H, W, Ho, Wo, stride, up, ksize=ksize)
+    return ConvGeom(L.MODE_CONV3X3, H, W, Ho, Wo, stride, up, ksize=ksize, dil=dil)
 
 
 def convt3_geom(T, HW):
@@ -139,6 +139,7 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     a.mode = geom.mode
     a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up = geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up
     a.ksize = geom.ksize
+    a.dil = geom.dil
     a.T, a.HW = geom.T, geom.HW
     a.rv_div, a.rv_mul, a.rv_mod_in, a.rv_mod_out = rv
     a.act = act
@@ -468,4 +469,52 @@ def flow_to_image(flow_hw2):
     ws = torch.empty((lib.mofa_flow_to_image_ws_bytes(H, W),), dtype=torch.uint8, device=flow_hw2.device)
     out = torch.empty((H, W, 3), dtype=torch.uint8, device=flow_hw2.device)
     L.check(lib.mofa_flow_to_image_u8(L.ptr(flow_hw2), L.ptr(out), H, W, L.ptr(ws), L.stream_ptr()), "mofa_flow_to_image_u8")
+    return out
+
+
+# ---- CMP sparse-to-dense motion encoder pieces ----------------------------------------------
+def pool2d(x, nimg, H, W, C, k, stride, pad=0, mode="max", out=None):
+    """token-major fp16 [nimg*H*W, ld>=C] -> [nimg*Ho*Wo, ld_out]; nn.MaxPool2d / nn.AvgPool2d semantics."""
+    lib = L.load()
+    _chk(x, F16)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty((nimg * Ho * Wo, C), dtype=F16, device=x.device)
+    assert x.shape[0] == nimg * H * W and out.shape[0] == nimg * Ho * Wo
+    L.check(lib.mofa_pool2d_f16(L.ptr(x), L.ptr(out), nimg, H, W, C, _ld(x), _ld(out), k, stride, pad, 0 if mode == "max" else 1,
+                                L.stream_ptr()), "mofa_pool2d_f16")
+    return out, Ho, Wo
+
+
+def resize_bilinear_ac(x, nimg, H, W, C, Ho, Wo, out=None):
+    """token-major fp16 maps, F.interpolate(mode='bilinear', align_corners=True)"""
+    lib = L.load()
+    _chk(x, F16)
+    if out is None:
+        out = torch.empty((nimg * Ho * Wo, C), dtype=F16, device=x.device)
+    assert x.shape[0] == nimg * H * W and out.shape[0] == nimg * Ho * Wo
+    L.check(lib.mofa_resize_bilinear_ac_f16(L.ptr(x), L.ptr(out), nimg, H, W, Ho, Wo, C, _ld(x), _ld(out), L.stream_ptr()),
+            "mofa_resize_bilinear_ac_f16")
+    return out
+
+
+def resize_bilinear_ac_f32(x, Ho, Wo):
+    """fp32 [..., H, W] planes -> [..., Ho, Wo], align_corners=True"""
+    lib = L.load()
+    _chk(x, F32)
+    H, W = x.shape[-2:]
+    x = x.contiguous()
+    y = torch.empty(tuple(x.shape[:-2]) + (Ho, Wo), dtype=F32, device=x.device)
+    L.check(lib.mofa_resize_bilinear_ac_f32(L.ptr(x), L.ptr(y), x.numel() // (H * W), H, W, Ho, Wo, L.stream_ptr()),
+            "mofa_resize_bilinear_ac_f32")
+    return y
+
+
+def flow_expectation(logits, nimg, H, W, nbins, fmax):
+    """fp16 logits [nimg*H*W, ld >= 2*nbins] -> fp32 flow [nimg, 2, H, W] (Fuser.convert_flow)"""
+    lib = L.load()
+    _chk(logits, F16)
+    out = torch.empty((nimg, 2, H, W), dtype=F32, device=logits.device)
+    L.check(lib.mofa_flow_expectation_f16(L.ptr(logits), L.ptr(out), nimg, H * W, _ld(logits), nbins, float(fmax), L.stream_ptr()),
+            "mofa_flow_expectation_f16")
     return out

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_igemm_args_struct_layout_matches_header():
     from mofa_video_amd.lib import IgemmArgs
-    # 7 pointers + 22 int32 + 3 float = 56 + 88 + 12 = 156 -> 160 with tail padding (8-byte aligned struct)
+    # 7 pointers + 22 int32 + 3 float + 1 int32 (dil) = 56 + 88 + 12 + 4 = 160 (8-byte aligned struct, no padding)
     assert ctypes.sizeof(IgemmArgs) == 160
     assert IgemmArgs.M.offset == 56 and IgemmArgs.ksize.offset == 112 and IgemmArgs.s_acc.offset == 144
 
