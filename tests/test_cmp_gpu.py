@@ -111,3 +111,27 @@ def test_get_flow_vs_oracle(models):
     e = rel_l2(got, ref)
     print(f"get_flow: rel-L2 {e:.3e}")
     assert tuple(got.shape) == (fb, fl, 2, H, W) and e < 2e-2
+
+
+def test_tracks_to_controlnet_flow_end_to_end(models):
+    """user tracks -> sparse drags (control.py) -> CMP (HIP) -> in/out-brush merge, against the same chain on the oracle"""
+    from mofa_video_amd import control
+    from oracle.cmp import get_flow as oget_flow
+    o, hm = models
+    work, H, W, T = 96, 64, 112, 5
+    tracks = [[(10, 12), (40, 30), (70, 80)], [(80, 20), (60, 50)]]
+    brush = torch.zeros(work, work, dtype=torch.uint8).numpy()
+    brush[:40, :40] = 255
+    d = control.tracking_points_to_drags(tracks, work, work, T, brush, work=work)
+    assert d["in_flag"] and d["out_flag"]
+    first = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(9))
+    got = control.controlnet_flow_from_drags(hm, first.to(DEV), d, H, W, motion_brush_mask=brush, work=work).cpu()
+    ff = F.interpolate(first, (work, work)).repeat(T - 1, 1, 1, 1).unsqueeze(0)
+    fin = oget_flow(o, ff, d["drag_in"].permute(0, 1, 4, 2, 3).float(), d["mask_in"].unsqueeze(2).repeat(1, 1, 2, 1, 1).float(),
+                    H, W, motion_brush_mask=brush)
+    fout = oget_flow(o, ff, d["drag_out"].permute(0, 1, 4, 2, 3).float(), d["mask_out"].unsqueeze(2).repeat(1, 1, 2, 1, 1).float(),
+                     H, W)
+    ref = control.merge_inmask_outmask(fin, fout)
+    e = rel_l2(got, ref)
+    print(f"tracks -> controlnet_flow: rel-L2 {e:.3e}")
+    assert tuple(got.shape) == (1, T - 1, 2, H, W) and e < 2e-2
