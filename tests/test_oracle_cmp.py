@@ -42,9 +42,9 @@ def test_cmp_inventory_and_run(cmp):
     image, sparse, mask = cmp_inputs(r["n"], r["h"], r["w"], r["seed"])
     with torch.no_grad():
         logits = cmp.model(image * 2 - 1, torch.cat([sparse, mask], dim=1))
-    assert rel_l2(logits[:, :, ::4, ::4], r["logits_stride4"]) < 1e-5
+    assert rel_l2(logits[:, :, ::4, ::4], r["logits_stride4"]) < 1e-4
     flow = cmp.run(image, sparse, mask)
-    assert tuple(flow.shape) == tuple(r["flow"].shape) and rel_l2(flow, r["flow"]) < 1e-5
+    assert tuple(flow.shape) == tuple(r["flow"].shape) and rel_l2(flow, r["flow"]) < 1e-4
 
 
 def test_get_flow(cmp):
@@ -53,4 +53,4 @@ def test_get_flow(cmp):
     image, sparse, mask = cmp_inputs(p["fl"], p["hs"], p["ws"], p["seed"])
     flow = get_flow(cmp, image.reshape(p["fb"], p["fl"], 3, p["hs"], p["ws"]), sparse.unsqueeze(0), mask.unsqueeze(0),
                     p["H"], p["W"], motion_brush_mask=p["brush"].numpy())
-    assert tuple(flow.shape) == tuple(p["flow"].shape) and rel_l2(flow, p["flow"]) < 1e-5
+    assert tuple(flow.shape) == tuple(p["flow"].shape) and rel_l2(flow, p["flow"]) < 1e-4

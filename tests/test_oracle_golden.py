@@ -7,6 +7,9 @@ What these fixtures pin: the in-tree reference code on the path -- scheduler, ad
 skip handling), FlowControlNetPipeline.__call__ (CFG, time-id quirk, Euler loop, chunked decode) and the
 state_dict key inventories.  The diffusers block arithmetic underneath was the oracle's own restatement when the
 fixtures were made (diffusers is not installable), so those blocks stay "parity unpinned" (DESIGN.md).
+
+Tolerances (rel-L2 1e-4 / 2e-4) only absorb the fp32 summation order of torch CPU kernels, which changes with the
+number of threads the host offers; an algorithmic deviation shows at >= 1e-2.
 """
 import os
 
@@ -99,9 +102,9 @@ def test_adapter_cnns(G, models):
     with torch.no_grad():
         ce = c.controlnet_cond_embedding(inp["cond"])
         fe = c.flow_encoder(ce)
-    assert rel_l2(ce, a["cond_embedding"]) < 1e-5
+    assert rel_l2(ce, a["cond_embedding"]) < 1e-4
     for x, y in zip(fe, a["flow_encoder"]):
-        assert rel_l2(x, y) < 1e-5
+        assert rel_l2(x, y) < 1e-4
 
 
 def test_flowcontrolnet_and_unet_forward(G, models):
@@ -136,6 +139,6 @@ def test_pipeline_loop_and_decode(G, models):
         lat = denoise(u, c, EulerDiscreteScheduler(), p["latents_in"], il, emb, p["cond"], p["flow"],
                       num_inference_steps=p["steps"])
         frames = decode_latents(v, p["final_latents"], p["T"], p["decode_chunk_size"])
-    assert rel_l2(lat, p["final_latents"]) < 5e-5, rel_l2(lat, p["final_latents"])
+    assert rel_l2(lat, p["final_latents"]) < 2e-4, rel_l2(lat, p["final_latents"])
     assert tuple(frames.shape) == tuple(p["frames"].shape)
-    assert rel_l2(frames, p["frames"]) < 1e-5
+    assert rel_l2(frames, p["frames"]) < 1e-4

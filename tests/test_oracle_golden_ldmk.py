@@ -41,9 +41,9 @@ def test_ldmk_inventory_and_forward(models):
                              controlnet_cond=torch.cat([inp["cond"]] * 2), controlnet_flow=torch.cat([inp["flow"]] * 2),
                              landmarks=torch.cat([lm] * 2), return_dict=False, conditioning_scale=a["conditioning_scale"])
     for i, (x, y) in enumerate(zip(list(dr) + [mr], list(a["down"]) + [a["mid"]])):
-        assert rel_l2(x, y) < 3e-5, (i, rel_l2(x, y))
+        assert rel_l2(x, y) < 2e-4, (i, rel_l2(x, y))
     for x, y in zip(om, a["occlusion_masks"]):
-        assert tuple(x.shape) == tuple(y.shape) and rel_l2(x, y) < 1e-5
+        assert tuple(x.shape) == tuple(y.shape) and rel_l2(x, y) < 1e-4
 
 
 def test_hybrid_pipeline(models):
@@ -56,7 +56,7 @@ def test_hybrid_pipeline(models):
     lat = denoise_hybrid(un, face, drag, EulerDiscreteScheduler(), p["latents_in"], il, emb, p["cond"], p["flow"],
                          p["landmarks"], p["drag_flow"], p["mask"], num_inference_steps=p["steps"],
                          ctrl_scale_traj=p["ctrl_scale_traj"], ctrl_scale_ldmk=p["ctrl_scale_ldmk"])
-    assert rel_l2(lat, p["final_latents"]) < 5e-5, rel_l2(lat, p["final_latents"])
+    assert rel_l2(lat, p["final_latents"]) < 2e-4, rel_l2(lat, p["final_latents"])
 
 
 def test_keypoint_window_loop(models):
@@ -72,4 +72,4 @@ def test_keypoint_window_loop(models):
     lat = denoise_keypoint_loop(un, face, EulerDiscreteScheduler(), p["latents_in"], il, emb, p["cond"], p["flow"],
                                 p["landmarks"], window_size=p["window_size"], stride=p["stride"],
                                 num_inference_steps=p["steps"])
-    assert rel_l2(lat, p["final_latents"]) < 5e-5, rel_l2(lat, p["final_latents"])
+    assert rel_l2(lat, p["final_latents"]) < 2e-4, rel_l2(lat, p["final_latents"])
