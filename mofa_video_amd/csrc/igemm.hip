@@ -29,14 +29,14 @@
 
 #include "common.h"
 
-struct RowGeo {
-    int img, oy, ox;  // conv3x3: image index and output pixel; convT3: oy = frame index within its clip
-    int m;            // global output row (or -1 when beyond M)
+struct RowGeo {   // two registers per DMA row group (the 192x128 tile keeps six of these live through the K loop)
+    int a;        // plain / convT3: global output row m; conv: image index; -1 when the row is beyond M
+    int b;        // conv: (oy << 16) | ox of the output pixel; convT3: frame index within its clip
 };
 
 __device__ __attribute__((aligned(128))) f16 g_zero_page[128];  // source of out-of-image taps / rows beyond M
 
-#ifdef MOFA_IGEMM_TRACE   // tools/igemm_trace.hip: per-workgroup tick sums: [0] first-tile prologue, [1] K loops, [2] epilogues, [3] tiles
+#ifdef MOFA_IGEMM_TRACE   // tools/igemm_trace.hip: per-workgroup tick sums: [0] first-stage waits, [1] K loops, [2..6] epilogue parts, [3] tiles
 __device__ unsigned long long g_trace[8 * 1024];
 #define TRACE_DECL unsigned long long tr_t = __builtin_readcyclecounter(), tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define TRACE_ADD(slot) do { const unsigned long long t__ = __builtin_readcyclecounter(); tr_acc[slot] += t__ - tr_t; tr_t = t__; } while (0)
@@ -49,37 +49,39 @@ __device__ unsigned long long g_trace[8 * 1024];
 
 __device__ __forceinline__ RowGeo make_geo(const mofa_igemm_args& a, int m) {
     RowGeo g;
-    g.m = (m < a.M) ? m : -1;
-    g.img = 0; g.oy = 0; g.ox = 0;
+    g.a = (m < a.M) ? m : -1;
+    g.b = 0;
     if (a.mode == MOFA_MODE_CONV3X3) {
         const int hw = a.Hout * a.Wout;
         const int img = m / hw, rem = m - img * hw;
-        g.img = img; g.oy = rem / a.Wout; g.ox = rem - g.oy * a.Wout;
+        const int oy = rem / a.Wout;
+        g.a = (m < a.M) ? img : -1;
+        g.b = (oy << 16) | (rem - oy * a.Wout);
     } else if (a.mode == MOFA_MODE_CONVT3) {
-        g.oy = a.T > 0 ? (m / a.HW) % a.T : 0;
+        g.b = a.T > 0 ? (m / a.HW) % a.T : 0;
     }
     return g;
 }
 
 __device__ __forceinline__ const f16* x_src(const mofa_igemm_args& a, const RowGeo& g, int tap) {
-    if (g.m < 0) return nullptr;
+    if (g.a < 0) return nullptr;
     const f16* x = (const f16*)a.x;
     if (a.mode == MOFA_MODE_PLAIN) {
-        return x + (size_t)g.m * a.ldx;
+        return x + (size_t)g.a * a.ldx;
     } else if (a.mode == MOFA_MODE_CONV3X3) {
         const int ks = a.ksize > 0 ? a.ksize : 3;
         const int dil = a.dil > 0 ? a.dil : 1;
         const int ky = tap / ks, kx = tap - ky * ks;
-        const int vy = g.oy * a.stride + (ky - (ks >> 1)) * dil;
-        const int vx = g.ox * a.stride + (kx - (ks >> 1)) * dil;
+        const int vy = (g.b >> 16) * a.stride + (ky - (ks >> 1)) * dil;
+        const int vx = (g.b & 0xffff) * a.stride + (kx - (ks >> 1)) * dil;
         if (vy < 0 || vx < 0 || vy >= a.Hin * a.up || vx >= a.Win * a.up) return nullptr;
         const int iy = (a.up == 2) ? (vy >> 1) : vy;
         const int ix = (a.up == 2) ? (vx >> 1) : vx;
-        return x + ((size_t)(g.img * a.Hin + iy) * a.Win + ix) * a.ldx;
+        return x + ((size_t)(g.a * a.Hin + iy) * a.Win + ix) * a.ldx;
     } else {  // MOFA_MODE_CONVT3
-        const int tt = g.oy + tap - 1;
+        const int tt = g.b + tap - 1;
         if (a.T > 0 && (tt < 0 || tt >= a.T)) return nullptr;   // T == 0: unclipped, caller supplies halo frames
-        return x + ((size_t)g.m + (size_t)(tap - 1) * a.HW) * a.ldx;
+        return x + ((size_t)g.a + (size_t)(tap - 1) * a.HW) * a.ldx;
     }
 }
 
@@ -200,18 +202,19 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
     const bool c8 = n + 8 <= nout, c4 = n + 4 <= nout;        // N % 4 == 0: a piece is whole, half or empty
 
     // Residual / row-vector loads: UNCONDITIONAL 16-byte (8-byte off the wide path) loads from clamped addresses (rows
-    // beyond M and pieces beyond N are never stored), a whole 32-row accumulator tile (P passes) at a time, and one
-    // explicit wait + idle slots before the first consumer.  Compiler-placed waits are avoided on purpose: with the
-    // s_waitcnt vmcnt(0) directly in front of the first VALU read (two ds_read_b128 still returning) that read
-    // intermittently saw the pre-load register contents in lanes 48..63 on MI355X (tools/igemm_det.hip: 7 of 7 repeat
-    // launches differed, always rows 6/7 of a pass, dwords 0/2 of the loaded quad).
-    constexpr int REGS_PER_TILE = P * ((R1 ? 4 : 0) + (R2 ? 4 : 0) + (RV ? 8 : 0));
-    constexpr bool AHEAD = REGS_PER_TILE > 0 && REGS_PER_TILE <= 32;   // next tile's loads before this tile's stores
+    // beyond M and pieces beyond N are never stored), G passes at a time (a whole 32-row accumulator tile when the
+    // registers allow), waited for explicitly (settle) before the first consumer.  On 128-row tiles the next group is
+    // loaded before this group's stores go out (vmcnt retires in order: those loads never wait for the stores).
+    constexpr int RPPASS = (R1 ? 4 : 0) + (R2 ? 4 : 0) + (RV ? 8 : 0);      // VGPRs of one pass's loads
+    constexpr int BUDGET = MI == 2 ? 64 : 16;                               // the 192 / 256-row tiles have few spare VGPRs
+    constexpr int G = RPPASS == 0 ? P : (RPPASS * P <= BUDGET ? P : (2 * RPPASS <= BUDGET && P % 2 == 0 ? 2 : 1));
+    constexpr int NG = P / G;                                               // load groups per accumulator tile
+    constexpr bool AHEAD = MI == 2 && RPPASS > 0 && 2 * RPPASS * G <= BUDGET;
     const int n_lo = c4 ? n : 0, n_hi = c8 ? n + 4 : n_lo;
-    auto issue_tile_loads = [&](int i, PassLoads (&L)[P]) {
+    auto issue_group_loads = [&](int grp, PassLoads (&L)[G]) {             // grp = i * NG + gi
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            int m = mrow0 + i * 32 + p * RPP + lrow;
+        for (int p = 0; p < G; ++p) {
+            int m = mrow0 + (grp / NG) * 32 + ((grp % NG) * G + p) * RPP + lrow;
             m = m < a.M ? m : a.M - 1;
             if (R1) {
                 const f16* q = r1 + (size_t)m * a.ldr1;
@@ -237,16 +240,16 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
             }
         }
     };
-    auto settle = [&](PassLoads (&L)[P]) {               // all loads of the tile have landed; keep consumers away
+    auto settle = [&](PassLoads (&L)[G]) {               // all loads of the group have landed
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (R1 && R2 && RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1), "+v"(L[p].t2), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
-            else if (R1 && R2) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1), "+v"(L[p].t2) :: "memory");
-            else if (R1 && RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
-            else if (R2 && RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t2), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
-            else if (R1) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t1) :: "memory");
-            else if (R2) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].t2) :: "memory");
-            else if (RV) asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 3" : "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+        for (int p = 0; p < G; ++p) {
+            if (R1 && R2 && RV) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[p].t1), "+v"(L[p].t2), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+            else if (R1 && R2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[p].t1), "+v"(L[p].t2) :: "memory");
+            else if (R1 && RV) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[p].t1), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+            else if (R2 && RV) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[p].t2), "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
+            else if (R1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[p].t1) :: "memory");
+            else if (R2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[p].t2) :: "memory");
+            else if (RV) asm volatile("s_waitcnt vmcnt(0)" : "+v"(L[p].rv0), "+v"(L[p].rv1) :: "memory");
         }
     };
 
@@ -257,8 +260,8 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
     // repeat launches differed; with VGPR operands 0 of 7 for every epilogue kind).
     float s1v = a.s1, s2v = a.s2, saccv = a.s_acc;
     asm volatile("" : "+v"(s1v), "+v"(s2v), "+v"(saccv));
-    PassLoads LA[P], LB[P];                               // this tile's / (AHEAD) the next tile's loads
-    if (REGS_PER_TILE > 0) issue_tile_loads(0, LA);
+    PassLoads LA[G], LB[G];                               // this group's / (AHEAD) the next group's loads
+    if (RPPASS > 0) issue_group_loads(0, LA);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         // ---- phase 1: raw accumulators, fragment layout -> slab (same-wave DS operations execute in order) ----
@@ -272,64 +275,68 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
                 *(f32x4*)(slab + slab_off(l31, j * 8 + 2 * q + lh)) = v;
             }
         TRACE_ADD(5);
-        PassLoads (&L)[P] = (AHEAD && (i & 1)) ? LB : LA;
-        if (REGS_PER_TILE > 0) {
-            if (!AHEAD && i > 0) issue_tile_loads(i, LA);
-            settle(L);
-            // the next tile's loads go out before this tile's stores and so never wait for them
-            if (AHEAD && i + 1 < MI) issue_tile_loads(i + 1, (i & 1) ? LA : LB);
-        }
-        // ---- phase 2: P passes of RPP rows; a lane owns 8 consecutive output columns of one row ----
+        // ---- phase 2: P passes of RPP rows in NG load groups; a lane owns 8 consecutive output columns of one row ----
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int row = p * RPP + lrow;
-            const int m = mrow0 + i * 32 + row;
-            float v[8];
-            {
-                const f32x4 v0 = *(const f32x4*)(slab + slab_off(row, 2 * lc));
-                const f32x4 v1 = *(const f32x4*)(slab + slab_off(row, 2 * lc + 1));
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+        for (int gi = 0; gi < NG; ++gi) {
+            const int grp = i * NG + gi;
+            PassLoads (&L)[G] = (AHEAD && (grp & 1)) ? LB : LA;
+            if (RPPASS > 0) {
+                if (!AHEAD && grp > 0) issue_group_loads(grp, LA);
+                settle(L);
+                if (AHEAD && grp + 1 < MI * NG) issue_group_loads(grp + 1, (grp & 1) ? LA : LB);
             }
-            if (GEGLU) {
-                const f32x4 g0 = *(const f32x4*)(slab + slab_off(row, 8 + 2 * lc));
-                const f32x4 g1 = *(const f32x4*)(slab + slab_off(row, 9 + 2 * lc));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = saccv * (v[e] + bias[0][e]) * gelu_erf_f(saccv * (g0[e] + bias[2][e]));
-                    v[4 + e] = saccv * (v[4 + e] + bias[1][e]) * gelu_erf_f(saccv * (g1[e] + bias[3][e]));
+            for (int pg = 0; pg < G; ++pg) {
+                const int p = gi * G + pg;
+                const int row = p * RPP + lrow;
+                const int m = mrow0 + i * 32 + row;
+                float v[8];
+                {
+                    const f32x4 v0 = *(const f32x4*)(slab + slab_off(row, 2 * lc));
+                    const f32x4 v1 = *(const f32x4*)(slab + slab_off(row, 2 * lc + 1));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
                 }
-            } else {
+                if (GEGLU) {
+                    const f32x4 g0 = *(const f32x4*)(slab + slab_off(row, 8 + 2 * lc));
+                    const f32x4 g1 = *(const f32x4*)(slab + slab_off(row, 9 + 2 * lc));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x0 = v[e] + bias[0][e], x1 = v[4 + e] + bias[1][e];
-                    if (RV) { x0 += L[p].rv0[e]; x1 += L[p].rv1[e]; }
-                    x0 *= saccv; x1 *= saccv;
-                    if (R1) { x0 += s1v * (float)L[p].t1[e]; x1 += s1v * (float)L[p].t1[4 + e]; }
-                    if (R2) { x0 += s2v * (float)L[p].t2[e]; x1 += s2v * (float)L[p].t2[4 + e]; }
-                    v[e] = x0; v[4 + e] = x1;
-                }
-                if (a.act == MOFA_ACT_SILU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-                } else if (a.act == MOFA_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-                }
-            }
-            if (m < a.M && c4) {
-                f16* po = out + (size_t)m * a.ldo + n;
-                if (WIDE) {
-                    f16x8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-                    *(f16x8*)po = o;
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = saccv * (v[e] + bias[0][e]) * gelu_erf_f(saccv * (g0[e] + bias[2][e]));
+                        v[4 + e] = saccv * (v[4 + e] + bias[1][e]) * gelu_erf_f(saccv * (g1[e] + bias[3][e]));
+                    }
                 } else {
-                    const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                    *(f16x4*)po = o;
-                    if (c8) {
-                        const f16x4 o2 = {(f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
-                        *(f16x4*)(po + 4) = o2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x0 = v[e] + bias[0][e], x1 = v[4 + e] + bias[1][e];
+                        if (RV) { x0 += L[pg].rv0[e]; x1 += L[pg].rv1[e]; }
+                        x0 *= saccv; x1 *= saccv;
+                        if (R1) { x0 += s1v * (float)L[pg].t1[e]; x1 += s1v * (float)L[pg].t1[4 + e]; }
+                        if (R2) { x0 += s2v * (float)L[pg].t2[e]; x1 += s2v * (float)L[pg].t2[4 + e]; }
+                        v[e] = x0; v[4 + e] = x1;
+                    }
+                    if (a.act == MOFA_ACT_SILU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
+                    } else if (a.act == MOFA_ACT_RELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    }
+                }
+                if (m < a.M && c4) {
+                    f16* po = out + (size_t)m * a.ldo + n;
+                    if (WIDE) {
+                        f16x8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
+                        *(f16x8*)po = o;
+                    } else {
+                        const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+                        *(f16x4*)po = o;
+                        if (c8) {
+                            const f16x4 o2 = {(f16)v[4], (f16)v[5], (f16)v[6], (f16)v[7]};
+                            *(f16x4*)(po + 4) = o2;
+                        }
                     }
                 }
             }
@@ -469,12 +476,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
             }
             const char* sb = smem + cur * STB;
             char* nb = smem + nxt * STB;
-            constexpr int OPK = (XI + WI) / (BKS / 16);      // DMA instructions per MFMA group
-            static_assert(OPK * (BKS / 16) == XI + WI, "DMA instructions must divide over the MFMA groups");
+            constexpr int OPS = XI + WI, NG = BKS / 16;      // DMA instructions per stage, MFMA groups per stage
 #pragma unroll
-            for (int kk = 0; kk < BKS / 16; ++kk) {
+            for (int kk = 0; kk < NG; ++kk) {
 #pragma unroll
-                for (int o = kk * OPK; o < (kk + 1) * OPK; ++o) {
+                for (int o = kk * OPS / NG; o < (kk + 1) * OPS / NG; ++o) {
                     if (o < XI) {
                         const f16* sp = xs[o] ? xs[o] + ikc * BKS + xoff[o] : (const f16*)g_zero_page;
                         glds16(sp, nb + (wave * XI + o) * 1024);
@@ -568,7 +574,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if ((a->stride != 1 && a->stride != 2) || (a->up != 1 && a->up != 2)) return MOFA_EINVAL;
         if (a->ksize != 0 && a->ksize != 1 && a->ksize != 3 && a->ksize != 5 && a->ksize != 7) return MOFA_EINVAL;
         if (a->dil < 0 || (a->dil > 1 && a->up != 1)) return MOFA_EINVAL;
-        if (a->M % (a->Hout * a->Wout) != 0) return MOFA_EINVAL;
+        if (a->M % (a->Hout * a->Wout) != 0 || a->Hout > 65535 || a->Wout > 65535) return MOFA_EINVAL;
     }
     if (a->mode == MOFA_MODE_CONVT3 && (a->T < 0 || a->HW <= 0 || (a->T > 0 && a->M % (a->T * a->HW) != 0)))
         return MOFA_EINVAL;
@@ -584,11 +590,12 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     {igemm_f16_kernel<WM, WN, MI, 0>, igemm_f16_kernel<WM, WN, MI, 1>, igemm_f16_kernel<WM, WN, MI, 2>,                \
      igemm_f16_kernel<WM, WN, MI, 3>, igemm_f16_kernel<WM, WN, MI, 4>, igemm_f16_kernel<WM, WN, MI, 5>,                \
      igemm_f16_kernel<WM, WN, MI, 6>, igemm_f16_kernel<WM, WN, MI, 7>, igemm_f16_kernel<WM, WN, MI, 8>}
-    static const Cfg cfgs[2] = {
+    static const Cfg cfgs[3] = {
         {IGEMM_KINDS(2, 2, 2), 128, 128, 256, 2 * 256 * 128, 2},   // 128^2 tile, 2 workgroups per CU
         {IGEMM_KINDS(2, 4, 4), 256, 256, 512, 2 * 512 * 128, 1},   // 256^2 tile, 1 workgroup per CU
+        {IGEMM_KINDS(2, 2, 3), 192, 128, 256, 2 * 320 * 128, 2},   // 192x128 tile: 2 x 80 KB = the whole LDS of a CU
     };
-    static int variant = -1;   // -1 unset, 0 / 1 forced configuration (MOFA_IGEMM_CFG=2 / 3), 100 = auto
+    static int variant = -1;   // -1 unset, 0 / 1 / 2 forced configuration (MOFA_IGEMM_CFG=2 / 3 / 4), 100 = auto
     static int n_cu = 256;
     if (variant == -1) {
         const char* e2 = getenv("MOFA_IGEMM_CFG");
@@ -601,7 +608,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             n_cu = cus;
-        variant = (v == 2) ? 0 : (v == 3 ? 1 : 100);
+        variant = (v == 2) ? 0 : (v == 3 ? 1 : (v == 4 ? 2 : 100));
     }
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const long long Ktot = (long long)taps * a->Cin;
@@ -616,7 +623,15 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         ci = big ? 1 : 0;
     }
     const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
-    if (variant == 100 && kind != 0 && kind != 8) ci = 0;      // the 256x256 tile has no registers for residual loads
+    if (variant == 100) {
+        if (ci == 1 && kind != 0 && kind != 8) ci = 0;         // the 256x256 tile has no registers for residual loads
+        if (ci == 0) {
+            // 192x128 (two workgroups fill the CU's 160 KB of LDS exactly): 17 % less fill and LDS-read traffic per flop
+            // than 128x128 and 50 % more MFMA work per barrier -- 5-20 % faster wherever its grid still fills the chip
+            const int t192 = cdiv(a->M, 192);
+            if ((long long)t192 * 192 * 16 <= (long long)a->M * 17 && (long long)t192 * cdiv(a->N, 128) >= 2LL * n_cu) ci = 2;
+        }
+    }
     const Cfg& c = cfgs[ci];
     const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
     const long long nt = (long long)tilesM * tilesN;
