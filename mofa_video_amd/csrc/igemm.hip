@@ -612,24 +612,28 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     }
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const long long Ktot = (long long)taps * a->Cin;
+    const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
     int ci = variant;
     if (variant == 100) {
-        // 256x256 tiles halve the global->LDS fill traffic per flop; use them when the column count fills them
-        // (<= 1/8 padding waste), the grid still covers the chip and N is wide relative to K (GEGLU / QKV projections);
-        // 128x128 (2 workgroups per CU) otherwise (profiles/r01_igemm_config_sweep.md)
-        const int t256m = cdiv(a->M, 256), t256n = cdiv(a->N, 256);
-        const bool big = (long long)t256n * 256 * 8 <= (long long)a->N * 9 && t256m * t256n >= 256 &&
-                         (long long)a->N >= 2 * Ktot;
-        ci = big ? 1 : 0;
-    }
-    const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
-    if (variant == 100) {
-        if (ci == 1 && kind != 0 && kind != 8) ci = 0;         // the 256x256 tile has no registers for residual loads
-        if (ci == 0) {
-            // 192x128 (two workgroups fill the CU's 160 KB of LDS exactly): 17 % less fill and LDS-read traffic per flop
-            // than 128x128 and 50 % more MFMA work per barrier -- 5-20 % faster wherever its grid still fills the chip
-            const int t192 = cdiv(a->M, 192);
-            if ((long long)t192 * 192 * 16 <= (long long)a->M * 17 && (long long)t192 * cdiv(a->N, 128) >= 2LL * n_cu) ci = 2;
+        // Tile choice = the cheapest of (rounds of resident workgroups) x (CU time of one round ~ workgroups per CU x tile
+        // area x measured relative cost per flop):
+        //   128x128  1.00  two workgroups per CU
+        //   192x128  0.86  two workgroups fill the CU's 160 KB of LDS exactly; 17 % less fill / LDS-read traffic per flop,
+        //                  50 % more MFMA work per barrier (tools/igemm_trace: K step 2450 vs 1950 ticks for 1.5x the work)
+        //   256x256  0.78  one workgroup per CU, half the fill traffic; only where N is wide relative to K (GEGLU / QKV
+        //                  projections: profiles/r01_igemm_config_sweep.md) and the epilogue has no residual loads (registers)
+        // Rounds count the padding waste of partial tiles and the idle slots of the last round (e.g. M = 7200: 570 tiles of
+        // 128x128 need two rounds of 512 slots, 380 tiles of 192x128 one).
+        static const double rel[3] = {1.00, 0.78, 0.86};
+        double best = 0;
+        ci = 0;
+        for (int k = 0; k < 3; ++k) {
+            if (k == 1 && (!(kind == 0 || kind == 8) || (long long)a->N < 2 * Ktot)) continue;
+            const long long t = (long long)cdiv(a->M, cfgs[k].tm) * cdiv(a->N, cfgs[k].tn);
+            const long long slots_k = (long long)n_cu * cfgs[k].wg_per_cu;
+            // a round of co-resident workgroups takes wg_per_cu x (tile area x relative cost) of CU time
+            const double cost = (double)((t + slots_k - 1) / slots_k) * cfgs[k].tm * cfgs[k].tn * rel[k] * cfgs[k].wg_per_cu;
+            if (k == 0 || cost < best) { best = cost; ci = k; }
         }
     }
     const Cfg& c = cfgs[ci];
