@@ -196,8 +196,8 @@ class FlowControlNetPipeline:
 # =========================================================================================================
 class HybridFlowControlNetPipeline(FlowControlNetPipeline):
     def __init__(self, vae=None, image_encoder=None, unet=None, face_controlnet=None, drag_controlnet=None,
-                 scheduler=None, feature_extractor=None):
-        super().__init__(vae, image_encoder, unet, face_controlnet, scheduler, feature_extractor)
+                 scheduler=None, feature_extractor=None, parallel=None):
+        super().__init__(vae, image_encoder, unet, face_controlnet, scheduler, feature_extractor, parallel=parallel)
         self.face_controlnet, self.drag_controlnet = face_controlnet, drag_controlnet
 
     @torch.no_grad()
@@ -220,8 +220,21 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
         timesteps = sch.timesteps
         lat = self.prepare_latents(1, T, unet.config.in_channels, height, width, generator, latents).reshape(T, 4, h, w).contiguous()
         cond = _to_tensor_image(controlnet_condition, height, width, dev)
-        cf = face.prepare_condition(cond[:1], controlnet_flow.to(dev, torch.float32)[:1], landmarks[:1])
-        cd = drag.prepare_condition(cond[:1], drag_flow.to(dev, torch.float32)[:1])
+        # frame sharding exactly as in FlowControlNetPipeline.__call__ (2-way CFG x frame shards)
+        par = self.parallel
+        lay = par.lay if par is not None else None
+        if lay is not None:
+            assert lay.T == T, "Layout was built for a different frame count"
+        f0, f1 = (lay.f0, lay.f1) if lay is not None else (0, T)
+        Tl = f1 - f0
+        Bl = lay.B_loc if lay is not None else 2
+        half = lay.half if lay is not None else None
+        fpar = par if (lay is not None and lay.sharded_frames) else None
+        cf = face.prepare_condition(cond[:1], controlnet_flow.to(dev, torch.float32)[:1], landmarks[:1], frames=(f0, f1))
+        cd = drag.prepare_condition(cond[:1], drag_flow.to(dev, torch.float32)[:1], frames=(f0, f1))
+        lat = lat[f0:f1].contiguous()
+        gspan = (max_guidance_scale - min_guidance_scale) / max(T - 1, 1)
+        g0, g1 = min_guidance_scale + gspan * f0, min_guidance_scale + gspan * (f1 - 1)
         # user mask, nearest-resized to every residual resolution (:481, :488) -- timestep-invariant
         m = mask.to(dev, torch.float32).reshape(1, height, width)
         masks = {}
@@ -230,28 +243,47 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
             masks[hh * ww] = ops.resize_nearest_f32(m, hh, ww).reshape(-1).contiguous()
             hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
-        c_f, c_d, c_u = Ctx(2, T), Ctx(2, T), Ctx(2, T)
-        x_in = torch.zeros((2 * T * h * w, unet.in_ld), dtype=torch.float16, device=dev)
+        c_f, c_d, c_u = Ctx(Bl, Tl), Ctx(Bl, Tl), Ctx(Bl, Tl)
+        rows = Tl * h * w
+        x_in = torch.zeros((2 * rows, unet.in_ld), dtype=torch.float16, device=dev)
+        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
         for i, t in enumerate(timesteps):
             sigma, sigma_next = sch.sigma_pair(i)
             ops.prepare_model_input(lat, il, x_in, sigma)
-            face.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_f)
-            df, mf = face.forward_tokens(x_in, c_f, h, w, cf, ctrl_scale_ldmk)
-            drag.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_d)
-            dd, md = drag.forward_tokens(x_in, c_d, h, w, cd, ctrl_scale_traj)
+            face.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_f, half=half, par=fpar)
+            df, mf = face.forward_tokens(x_loc, c_f, h, w, cf, ctrl_scale_ldmk)
+            drag.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_d, half=half, par=fpar)
+            dd, md = drag.forward_tokens(x_loc, c_d, h, w, cd, ctrl_scale_traj)
             down = []
             for a, b in zip(df, dd):
-                hw = a.shape[0] // (2 * T)
+                hw = a.shape[0] // (Bl * Tl)
                 down.append(ops.mask_blend(a, b, masks[hw], hw))
-            hw = mf.shape[0] // (2 * T)
+            hw = mf.shape[0] // (Bl * Tl)
             mid = ops.mask_blend(mf, md, masks[hw], hw)
-            unet.make_ctx(float(t), emb, added_time_ids, 2, T, base=c_u)
-            noise = unet.forward_tokens(x_in, c_u, h, w, down, mid)
-            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
+            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_u, half=half, par=fpar)
+            noise = unet.forward_tokens(x_loc, c_u, h, w, down, mid)
+            if Bl == 1:
+                noise = par.gather_cfg(noise)
+            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
+        if fpar is not None:
+            lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
         latents_out = lat.reshape(1, T, 4, h, w)
-        frames = latents_out if output_type == "latent" else decode_latents(self.vae, latents_out, T, decode_chunk_size)
-        if output_type not in ("latent", "raw"):
-            frames = tensor2vid(frames, None, output_type=output_type)
+        if output_type == "latent":
+            frames = latents_out
+        elif lay is None or lay.world == 1:
+            frames = decode_latents(self.vae, latents_out, T, decode_chunk_size)
+            if output_type != "raw":
+                frames = tensor2vid(frames, None, output_type=output_type)
+        else:                                             # VAE chunks dealt round-robin, as in FlowControlNetPipeline
+            frames = []
+            sf = 1.0 / self.vae.config.scaling_factor
+            for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
+                if ci % lay.world == lay.rank:
+                    z = latents_out[0, s0:s0 + decode_chunk_size]
+                    fr = self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)
+                    if output_type != "raw":
+                        fr = tensor2vid(fr.permute(1, 0, 2, 3).unsqueeze(0), None, output_type=output_type)[0]
+                    frames.append((s0, fr))
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)

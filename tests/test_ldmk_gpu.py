@@ -103,3 +103,51 @@ def test_keypoint_window_loop(models):
     e = rel_l2(out, ref)
     print(f"keypoint loop latents after 2 steps: rel-L2 {e:.3e}")
     assert e < 2e-2, e
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_hybrid_pipeline_frame_sharded_equals_single_rank(models, world):
+    """Hybrid (two adapters + mask blend) on virtual ranks of this GPU: 2-way CFG x frame shards must reproduce the
+    single-rank latents (only the GroupNorm summation order differs)."""
+    import threading
+
+    from mofa_video_amd.parallel import FrameParallel, Layout, ThreadComm, ThreadWorld
+    from mofa_video_amd.pipeline import HybridFlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    of, od, ou, hf, hd, hu = models
+    T = 4
+    inp = synthetic_inputs(T, H, W, cross_dim=CROSS, seed=43)
+    lm = synthetic_landmarks(T, H, W, seed=44)
+    drag_flow = synthetic_inputs(T, H, W, cross_dim=CROSS, seed=45)["flow"] * 0.5
+    mask = torch.zeros(1, 1, H, W)
+    mask[:, :, H // 4:3 * H // 4, W // 4:3 * W // 4] = 1.0
+
+    def run(parallel=None):
+        pipe = HybridFlowControlNetPipeline(unet=hu, face_controlnet=hf, drag_controlnet=hd, scheduler=EulerDiscreteScheduler(),
+                                            parallel=parallel)
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV),
+                    drag_flow=drag_flow, mask=mask, height=H, width=W, num_frames=T, num_inference_steps=2,
+                    latents=inp["latents"], output_type="latent", ctrl_scale_traj=0.8, ctrl_scale_ldmk=1.1,
+                    image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames
+    ref = run()
+    tw = ThreadWorld(world)
+    results, errors = [None] * world, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            results[r] = run(FrameParallel(Layout(world, r, T), ThreadComm(tw, r)))
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            for b in tw.barriers.values():
+                b.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    for r, o in enumerate(results):
+        e = rel_l2(o, ref)
+        print(f"hybrid world {world} rank {r}: latents rel-L2 vs single rank {e:.3e}")
+        assert tuple(o.shape) == tuple(ref.shape) and e < 2e-3, (r, e)
