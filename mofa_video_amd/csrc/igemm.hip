@@ -4,13 +4,15 @@
 //   out[m, n] = act( s_acc * (sum_tap sum_k X[src(m,tap), k] * W[n, tap*Cin + k] + bias[n] + rowvec[idx(m), n])
 //                    + s1 * R1[m, n] + s2 * R2[m, n] )
 //
-// One PERSISTENT workgroup per CU slot walks output tiles (128x128 with 4 waves, 2 workgroups per CU; or 256x256 with
-// 8 waves, 1 per CU).  Each wave owns MI x 2 MFMA 32x32x16 f16 tiles with fp32 accumulators.  The MFMA "A" operand is
+// One PERSISTENT workgroup per CU slot walks output tiles (128x128 or 192x128 with 4 waves, 2 workgroups per CU; or
+// 256x256 with 8 waves, 1 per CU; the launcher picks by a small cost model).  Each wave owns MI x 2 MFMA 32x32x16 f16
+// tiles with fp32 accumulators.  The MFMA "A" operand is
 // the WEIGHT tile and the "B" operand the ACTIVATION tile, so an accumulator lane owns one output row.  K is walked
 // tap-major in steps of 64 (128-byte LDS rows = whole cache lines per row); zero padding of the convolution is realised
 // by sourcing the rows of an out-of-image tap from a zero page.
 //
-// K loop: a 2-stage LDS ring filled by direct-to-LDS DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR staging).
+// K loop: a 2-stage LDS ring filled by direct-to-LDS DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR staging), the
+// DMA instructions of the next stage interleaved with the four MFMA groups of the current one.
 // The LDS image is lane-linear; bank conflicts of the ds_read_b128 fragment reads are removed by an XOR swizzle applied
 // on the SOURCE address and again on the read (cdna guide, rule 21).  The stream of stages runs ACROSS tiles: the last
 // K step of a tile issues stage 0 of the workgroup's next tile, so the DMA latency of the next tile hides under the
@@ -20,9 +22,12 @@
 //
 // Epilogue: each wave transposes its 32 x 64 accumulator block through a private 8 KB XOR-swizzled LDS slab (inside the
 // ring stage the K loop has just finished with) so that a lane owns 8 consecutive columns of one row; bias, row vector,
-// residuals, GEGLU product and activation are applied in that layout with 16-byte global accesses.  Residual loads run
-// one pass ahead of the stores (vmcnt retires in order on gfx9: a load issued before a store never waits for it).  The
-// kernel is templated on the epilogue kind (residuals / row vector / GEGLU) so the memory operations per pass are static.
+// residuals, GEGLU product and activation are applied in that layout with 16-byte global accesses.  Residual /
+// row-vector loads are issued a group of passes at a time, on 128-row tiles one group ahead of the stores (vmcnt retires
+// in order on gfx9: a load issued before a store never waits for it).  The kernel is templated on the epilogue kind
+// (residuals / row vector / GEGLU) so the memory operations per pass are static.
+// Environment: MOFA_IGEMM_CFG=2|3|4 forces the 128x128 | 256x256 | 192x128 tile; MOFA_IGEMM_PERSIST=0 launches one
+// workgroup per tile (A/B of the persistent walk).
 // Earlier variants (register staging, 64-byte rows, deeper rings, 256x128 tiles) and their measurements:
 // profiles/r01_igemm_config_sweep.md.
 #include <stdlib.h>
