@@ -228,3 +228,25 @@ class FrameParallel:
         """noise [T_loc*HW, 4] of this half -> [2*T_loc*HW, 4] (unconditional first)"""
         got = self.comm.all_gather(noise, self.lay.pair_group)
         return torch.cat(got, 0) if len(got) > 1 else got[0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+class WindowParallel:
+    """Long-video (Keypoint window loop) sharding: the DISTINCT temporal windows of one denoise step are independent
+    (MOFA-Video-Keypoint/pipeline/svdxt_pipeline_ctrlnet_loop.py:470-511), so they are dealt round-robin to the ranks;
+    after every round one all-gather hands every rank every stepped window, and all ranks apply the same overlap
+    averaging.  No other exchange: each window runs the whole adapter + UNet on its own 25 frames."""
+
+    def __init__(self, comm, rank, world):
+        self.comm, self.rank, self.world = comm, rank, world
+
+    def rounds(self, keys):
+        """keys: the distinct windows in view order -> list of rounds, each a list of ``world`` keys (None = idle slot)"""
+        out = []
+        for j in range(0, len(keys), self.world):
+            chunk = list(keys[j:j + self.world])
+            out.append(chunk + [None] * (self.world - len(chunk)))
+        return out
+
+    def gather(self, t):
+        return self.comm.all_gather_world(t)

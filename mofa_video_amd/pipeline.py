@@ -333,6 +333,8 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
                 conds[(t0, t1)] = cn.prepare_condition(cond[:1], flow[:1, t0 - 1:t1 - 1], lm)
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
         ctxs = {v: (Ctx(2, Tw), Ctx(2, Tw)) for v in conds}
+        distinct = list(conds)                                                     # distinct windows, in view order
+        wpar = self.parallel                                                       # parallel.WindowParallel or None
         x_in = torch.zeros((2 * Tw * h * w, unet.in_ld), dtype=torch.float16, device=dev)
         value = torch.empty_like(lat)
         fsz = 4 * h * w
@@ -341,17 +343,29 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
             count = [0] * N
             touched = [False] * N
             done = {}
+
+            def step_window(t0, t1):
+                lw = torch.cat([lat[0:1], lat[t0:t1]], dim=0).contiguous()            # frame 0 + window frames
+                ops.prepare_model_input(lw, il, x_in, sigma)
+                c_cn, c_un = ctxs[(t0, t1)]
+                cn.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_cn)
+                down, mid = cn.forward_tokens(x_in, c_cn, h, w, conds[(t0, t1)], controlnet_cond_scale)
+                unet.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_un)
+                noise = unet.forward_tokens(x_in, c_un, h, w, down, mid)
+                ops.cfg_euler_step_(lw, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
+                return lw
+            if wpar is None:
+                for key in distinct:
+                    done[key] = step_window(*key)
+            else:                                         # window-parallel: one window per rank and round
+                for rnd in wpar.rounds(distinct):
+                    mine = rnd[wpar.rank]
+                    lw = step_window(*mine) if mine is not None else torch.zeros((Tw,) + tuple(lat.shape[1:]),
+                                                                               dtype=lat.dtype, device=dev)
+                    for key, got in zip(rnd, wpar.gather(lw)):
+                        if key is not None:
+                            done[key] = got
             for idx, (t0, t1) in enumerate(views):
-                if (t0, t1) not in done:
-                    lw = torch.cat([lat[0:1], lat[t0:t1]], dim=0).contiguous()            # frame 0 + window frames
-                    ops.prepare_model_input(lw, il, x_in, sigma)
-                    c_cn, c_un = ctxs[(t0, t1)]
-                    cn.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_cn)
-                    down, mid = cn.forward_tokens(x_in, c_cn, h, w, conds[(t0, t1)], controlnet_cond_scale)
-                    unet.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_un)
-                    noise = unet.forward_tokens(x_in, c_un, h, w, down, mid)
-                    ops.cfg_euler_step_(lw, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
-                    done[(t0, t1)] = lw
                 lw = done[(t0, t1)]
                 # value[0:t1] += lw (first view) / value[t0:t1] += lw[1:] (others)   (:502-507)
                 dst0, src0 = (0, 0) if idx == 0 else (t0, 1)

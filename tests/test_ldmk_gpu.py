@@ -151,3 +151,44 @@ def test_hybrid_pipeline_frame_sharded_equals_single_rank(models, world):
         e = rel_l2(o, ref)
         print(f"hybrid world {world} rank {r}: latents rel-L2 vs single rank {e:.3e}")
         assert tuple(o.shape) == tuple(ref.shape) and e < 2e-3, (r, e)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_keypoint_loop_window_parallel_equals_single_rank(models, world):
+    """Keypoint long-video loop with its distinct windows dealt to virtual ranks (parallel.WindowParallel): every rank
+    must end with exactly the single-rank latents (same kernels on the same data, same averaging order)."""
+    import threading
+
+    from mofa_video_amd.parallel import ThreadComm, ThreadWorld, WindowParallel
+    from mofa_video_amd.pipeline import KeypointFlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    of, od, ou, hf, hd, hu = models
+    N, win, stride = 6, 4, 2
+    inp = synthetic_inputs(N, H, W, cross_dim=CROSS, seed=46)
+    lm = synthetic_landmarks(N, H, W, seed=47)
+
+    def run(parallel=None):
+        pipe = KeypointFlowControlNetPipeline(unet=hu, controlnet=hf, scheduler=EulerDiscreteScheduler(), parallel=parallel)
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=win,
+                    stride=stride, height=H, width=W, num_frames=N, num_inference_steps=2, latents=inp["latents"],
+                    output_type="latent", image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames
+    ref = run()
+    tw = ThreadWorld(world)
+    results, errors = [None] * world, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            results[r] = run(WindowParallel(ThreadComm(tw, r), r, world))
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            for b in tw.barriers.values():
+                b.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    for r, o in enumerate(results):
+        assert torch.equal(o, ref), (r, rel_l2(o, ref))
