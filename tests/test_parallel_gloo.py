@@ -91,3 +91,31 @@ def _worker(rank, world, port, T, HW, C):
 @pytest.mark.parametrize("world,T", [(2, 5), (4, 5), (4, 7)])
 def test_frame_parallel_exchanges_gloo(world, T):
     mp.spawn(_worker, args=(world, _free_port(), T, 6, 32), nprocs=world, join=True)
+
+
+def _window_worker(rank, world, port, nwin):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mofa_video_amd.parallel import WindowParallel
+        wp = WindowParallel(TorchComm(lambda r: Layout(world, r, 25)), rank, world)
+        keys = [(1 + 3 * i, 4 + 3 * i) for i in range(nwin)]
+        rounds = wp.rounds(keys)
+        assert [k for rnd in rounds for k in rnd if k is not None] == keys and all(len(r) == world for r in rounds)
+        done = {}
+        for rnd in rounds:
+            mine = rnd[rank]
+            t = torch.full((4, 3), float(mine[0]) if mine is not None else 0.0)
+            for key, got in zip(rnd, wp.gather(t)):
+                if key is not None:
+                    done[key] = got
+        assert sorted(done) == keys
+        for k, v in done.items():                 # every rank holds every window, each produced by its owner
+            assert torch.equal(v, torch.full((4, 3), float(k[0])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nwin", [(2, 3), (2, 4), (4, 3)])
+def test_window_parallel_gloo(world, nwin):
+    mp.spawn(_window_worker, args=(world, _free_port(), nwin), nprocs=world, join=True)
