@@ -1,8 +1,8 @@
 // Attention kernels for gfx950 (head_dim 64).
 //
 // mofa_attn_spatial_f16: flash-style self-attention over the S = h*w tokens of one frame.
-//   One workgroup = 4 waves = 128 query rows of one (frame, head); K and V^T tiles of 64 keys are
-//   staged through double-buffered LDS.  Scores are computed TRANSPOSED (S^T = K . Q^T, MFMA
+//   One workgroup = 4 waves = 128 (or 256: two 32-query blocks per wave) query rows of one (frame, head); K and V^T
+//   tiles of 64 keys are staged through double-buffered LDS.  Scores are computed TRANSPOSED (S^T = K . Q^T, MFMA
 //   32x32x16 f16) so every lane owns one query row: the softmax statistics are per-lane scalars
 //   (one cross-half exchange per tile) and the probabilities are already laid out as the B operand of
 //   O^T += V^T . P^T -- the k-slot -> key permutation of that MFMA is chosen to match the accumulator
@@ -10,13 +10,18 @@
 //
 // mofa_attn_temporal_f16: self-attention over the T <= 32 frames of one (clip, pixel, head); HBM-bound,
 //   one wave per sequence, VALU fp32.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define ATT_VSTR 68   // V^T tile row stride (halves): 136 B, conflict-free ds_read_b64
 #define ATT_TILE 64
 
 // D = head dim (64 or 128).  K tile row stride D+8 halves (144 / 272 B: conflict-free ds_read_b128).
-template <int D>
+// QB = 32-query blocks per wave (1 or 2).  With QB = 2 every K / V^T fragment read from LDS feeds two MFMAs and the
+// per-tile costs (tile loads, LDS store, barrier, 24 fragment reads) are paid once per 64 queries of a wave: used when
+// a frame has enough query rows to fill the chip with 256-row workgroups.
+template <int D, int QB>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                               const f16* __restrict__ vt, f16* __restrict__ out,
                                                               int heads, int S, int ldq, int ldk, int ldo, float c) {
@@ -31,27 +36,32 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int head = blockIdx.y, frame = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
 
     const f16* kbase = k + (size_t)frame * S * ldk + head * D;
     const f16* vbase = vt + ((size_t)(frame * heads + head) * D) * S;
 
     // Q fragments (B operand of S^T): lane (query l31, half lh) holds Q[q][16*kk + 8*lh .. +8)
-    f16x8 qf[KK];
+    f16x8 qf[QB][KK];
     const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    {
-        const int qi = q0 + l31;
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qi = q0 + b * 32 + l31;
         const f16* qp = q + ((size_t)frame * S + (qi < S ? qi : 0)) * ldq + head * D + lh * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) qf[kk] = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
+        for (int kk = 0; kk < KK; ++kk) qf[b][kk] = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
     }
 
-    f32x16 o[DB];
+    f32x16 o[QB][DB];
+    float m_run[QB], l_run[QB];
 #pragma unroll
-    for (int db = 0; db < DB; ++db)
+    for (int b = 0; b < QB; ++b) {
+        m_run[b] = -1e30f; l_run[b] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[b][db][r] = 0.f;
+    }
 
     // loader mapping: K tile = 64 keys x D/8 chunks(16 B); V^T tile = D rows x 8 chunks; NCH chunks per thread each
     constexpr int CPR = D / 8;
@@ -94,59 +104,67 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         const int k0 = t * ATT_TILE;
         if (t + 1 < ntiles) load_tile(k0 + ATT_TILE);
 
-        // ---- S^T tiles: s[ts][r] = score(key = k0 + 32*ts + (r&3) + 8*(r>>2) + 4*lh, query = l31) ----
-        f32x16 s[2];
+        // ---- S^T tiles: s[b][ts][r] = score(key = k0 + 32*ts + (r&3) + 8*(r>>2) + 4*lh, query = 32*b + l31) ----
+        f32x16 s[QB][2];
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[ts][r] = 0.f;
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[b][ts][r] = 0.f;
             const f16* kp = sKb + buf * ATT_TILE * ATT_KSTR + (ts * 32 + l31) * ATT_KSTR + lh * 8;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
                 const f16x8 kf = *(const f16x8*)(kp + kk * 16);
-                s[ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[ts], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < QB; ++b) s[b][ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][kk], s[b][ts], 0, 0, 0);
             }
         }
         // ---- mask (tail tile only) + online softmax (per-lane query row; the two halves hold disjoint keys) ----
         if (__builtin_amdgcn_readfirstlane(k0 + ATT_TILE > S)) {
             asm volatile("; tail tile" ::: "memory");   // keep this a real (wave-uniform) branch, not 64 selects per tile
 #pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + ts * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key >= S) s[b][ts][r] = -1e30f;
+                    }
+        }
+        f16x8 pf[QB][2][2];
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            float mx = s[b][0][0];
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][ts][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // the running max changes in few tiles once it has settled: rescale O only then (alpha == 1 exactly otherwise)
+            if (__any(mx > m_run[b])) {
+                const float m_new = fmaxf(m_run[b], mx);
+                const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * c);
+                m_run[b] = m_new;
+                l_run[b] *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[b][db][r] *= alpha;
+            }
+            const float mc = m_run[b] * c;
+            float psum = 0.f;
+#pragma unroll
             for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + ts * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key >= S) s[ts][r] = -1e30f;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[b][ts][r], c, -mc));   // raw v_exp_f32: arguments are <= 0
+                    psum += p;
+                    pf[b][ts][r >> 3][r & 7] = (f16)p;
                 }
+            l_run[b] += psum;
         }
-        float mx = s[0][0];
-#pragma unroll
-        for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[ts][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        // the running max changes in few tiles once it has settled: rescale O only then (alpha == 1 exactly otherwise)
-        if (__any(mx > m_run)) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int db = 0; db < DB; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
-        }
-        const float mc = m_run * c;
-        float psum = 0.f;
-        f16x8 pf[2][2];
-#pragma unroll
-        for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[ts][r], c, -mc));   // raw v_exp_f32: arguments are <= 0
-                psum += p;
-                pf[ts][r >> 3][r & 7] = (f16)p;
-            }
-        l_run += psum;
 
         // ---- O^T[d][q] += V^T[d][key] * P^T[key][q]; k-slot (8*lh + jj) of MFMA (ts,u) = key
         //      32*ts + 16*u + 4*lh + (jj&3) + 8*(jj>>2), identical for both operands ---------------
@@ -160,43 +178,46 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                     const f16x4 lo = *(const f16x4*)(vp + ts * 32 + u * 16);
                     const f16x4 hi = *(const f16x4*)(vp + ts * 32 + u * 16 + 8);
                     const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[ts][u], o[db], 0, 0, 0);
+#pragma unroll
+                    for (int b = 0; b < QB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b][ts][u], o[b][db], 0, 0, 0);
                 }
         }
         if (t + 1 < ntiles) store_tile(buf ^ 1);
         __syncthreads();
     }
 
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    const int qi = q0 + l31;
-    if (qi < S) {
-        f16* op = out + ((size_t)frame * S + qi) * ldo + head * D;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+    for (int b = 0; b < QB; ++b) {
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
+        const float inv = 1.0f / l_tot;
+        const int qi = q0 + b * 32 + l31;
+        if (qi < S) {
+            f16* op = out + ((size_t)frame * S + qi) * ldo + head * D;
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                f16x4 v;
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (f16)(o[db][4 * qd + e] * inv);
-                *(f16x4*)(op + db * 32 + 8 * qd + 4 * lh) = v;
-            }
+                for (int qd = 0; qd < 4; ++qd) {
+                    f16x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (f16)(o[b][db][4 * qd + e] * inv);
+                    *(f16x4*)(op + db * 32 + 8 * qd + 4 * lh) = v;
+                }
+        }
     }
 }
-
-template <int D>
+template <int D, int QB>
 static int launch_attn_spatial(const void* q, const void* k, const void* vt, void* out, int nframes, int heads, int S,
                                int ldq, int ldk, int ldo, float c, hipStream_t st) {
     constexpr int LDS = 2 * (ATT_TILE * (D + 8) + D * ATT_VSTR) * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess)
             return MOFA_ELAUNCH;
         attr_set = true;
     }
-    dim3 grid(cdiv(S, 128), heads, nframes);
-    hipLaunchKernelGGL(attn_spatial_kernel<D>, grid, dim3(256), LDS, st, (const f16*)q, (const f16*)k, (const f16*)vt,
+    dim3 grid(cdiv(S, 128 * QB), heads, nframes);
+    hipLaunchKernelGGL((attn_spatial_kernel<D, QB>), grid, dim3(256), LDS, st, (const f16*)q, (const f16*)k, (const f16*)vt,
                        (f16*)out, heads, S, ldq, ldk, ldo, c);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
@@ -207,8 +228,16 @@ extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* v
     if (!q || !k || !vt || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
     if (S % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
     const float c = scale * 1.4426950408889634f;
-    if (head_dim == 64) return launch_attn_spatial<64>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
-    if (head_dim == 128) return launch_attn_spatial<128>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
+    // 64 queries per wave (256-row workgroups: +6-7 % at S = 9216 / 2304) when S tiles by 256 with <= 1/16 waste and the
+    // grid still gives >= 4 workgroups per CU; MOFA_ATTN_QB=1|2 forces either
+    static int force_qb = -1;
+    if (force_qb < 0) { const char* e = getenv("MOFA_ATTN_QB"); force_qb = e ? atoi(e) : 0; }
+    const bool two = force_qb ? force_qb == 2
+                              : ((long long)cdiv(S, 256) * 256 * 16 <= (long long)S * 17 && (long long)cdiv(S, 256) * heads * nframes >= 1024);
+    if (head_dim == 64)
+        return two ? launch_attn_spatial<64, 2>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream)
+                   : launch_attn_spatial<64, 1>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
+    if (head_dim == 128) return launch_attn_spatial<128, 1>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
     return MOFA_EINVAL;
 }
 
