@@ -49,7 +49,8 @@ int mofa_version(void);
  * and the adapter's own convs (models/svdxt_featureflow_forward_controlnet_s2d_fixcmp_norefine.py:66-155).
  * ---------------------------------------------------------------------------------------- */
 enum { MOFA_MODE_PLAIN = 0, MOFA_MODE_CONV3X3 = 1, MOFA_MODE_CONVT3 = 2 };   /* CONV3X3 = k x k conv, k = ksize (1, 3, 5 or 7) */
-enum { MOFA_ACT_NONE = 0, MOFA_ACT_SILU = 1, MOFA_ACT_GEGLU_PAIR = 2, MOFA_ACT_RELU = 3 };
+enum { MOFA_ACT_NONE = 0, MOFA_ACT_SILU = 1, MOFA_ACT_GEGLU_PAIR = 2, MOFA_ACT_RELU = 3,
+       MOFA_ACT_GELU = 4 /* exact (erf) GELU: CLIP vision MLP, transformers CLIPMLP with hidden_act = "gelu" */ };
 
 typedef struct mofa_igemm_args {
     const void* x;      /* fp16 activations                                                  */
@@ -72,8 +73,12 @@ typedef struct mofa_igemm_args {
     int32_t act;        /* MOFA_ACT_*                                                        */
     float s_acc, s1, s2;
     int32_t dil;        /* MOFA_MODE_CONV3X3: tap dilation (0 means 1); the CMP encoder's de-strided ResNet stages use 2 and 4
-                         * (Traj/models/cmp/models/backbone/resnet.py:118-129).  Occupies the former tail padding: sizeof = 160 */
+                         * (Traj/models/cmp/models/backbone/resnet.py:118-129) */
+    int32_t pad;        /* MOFA_MODE_CONV3X3: MOFA_PAD_SAME (0) = dil*(k/2) on every side; MOFA_PAD_TRAILING (1) = no
+                         * leading padding, taps start at input pixel stride*o (diffusers Downsample2D(padding=0) of the
+                         * VAE encoder: F.pad(x, (0,1,0,1)) then a stride-2 conv).  sizeof(mofa_igemm_args) = 168     */
 } mofa_igemm_args;
+enum { MOFA_PAD_SAME = 0, MOFA_PAD_TRAILING = 1 };
 
 int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
 
@@ -212,6 +217,18 @@ int mofa_frames_postprocess_f32(const float* frames_nchw, void* out, int nframes
 int64_t mofa_flow_to_image_ws_bytes(int H, int W);
 int mofa_flow_to_image_u8(const float* flow_hw2, unsigned char* out_hw3, int H, int W, void* workspace,
                           mofa_stream_t stream);
+
+/* ---- image conditioning front end (the step before the loop) ------------------------------------------------
+ * _resize_with_antialiasing (MOFA-Video-Traj/pipeline/pipeline.py:531-562) = separable Gaussian blur with reflect
+ * padding (_gaussian_blur2d :632-645, _filter2d :587-610; x pass then y pass) + F.interpolate(bicubic, align_corners=True).
+ * fp32 planes [nplanes][H][W]; taps = k fp32 weights on the device; axis 1 = along W, 0 = along H; out != x. */
+int mofa_filter1d_reflect_f32(const float* x, float* out, const float* taps, int nplanes, int H, int W, int k, int axis,
+                              mofa_stream_t stream);
+int mofa_resize_bicubic_ac_f32(const float* x, float* out, int nplanes, int Hin, int Win, int Hout, int Wout,
+                               mofa_stream_t stream);
+/* operand of the CLIP patch embedding (transformers CLIPVisionEmbeddings.patch_embedding, stride = kernel = p):
+ * fp32 [nimg][C][H][W] -> fp16 [nimg*(H/p)*(W/p)][ld], column c*p*p + py*p + px, columns >= C*p*p zero */
+int mofa_patchify_f16(const float* x, void* out, int nimg, int C, int H, int W, int p, int ld, mofa_stream_t stream);
 
 /* ---- CMP sparse-to-dense motion encoder, non-convolution pieces (the step before the path) -----------------
  * Token-major fp16 maps [nimg*H*W][ld].  pool2d: nn.MaxPool2d (mode 0, padding ignored) / nn.AvgPool2d (mode 1)

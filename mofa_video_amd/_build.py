@@ -5,7 +5,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmofa_hip.so")
-SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip", "cmp_ops.hip"]
+SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip", "cmp_ops.hip",
+           "frontend.hip"]
 
 
 def _stale():

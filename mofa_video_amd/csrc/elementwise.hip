@@ -372,4 +372,4 @@ extern "C" int mofa_subsample_tokens_f16(const void* x, void* y, int n, int H, i
     return MOFA_OK;
 }
 
-extern "C" int mofa_version(void) { return 103; }
+extern "C" int mofa_version(void) { return 104; }

@@ -77,8 +77,9 @@ __device__ __forceinline__ const f16* x_src(const mofa_igemm_args& a, const RowG
         const int ks = a.ksize > 0 ? a.ksize : 3;
         const int dil = a.dil > 0 ? a.dil : 1;
         const int ky = tap / ks, kx = tap - ky * ks;
-        const int vy = (g.b >> 16) * a.stride + (ky - (ks >> 1)) * dil;
-        const int vx = (g.b & 0xffff) * a.stride + (kx - (ks >> 1)) * dil;
+        const int org = a.pad == MOFA_PAD_TRAILING ? 0 : (ks >> 1);
+        const int vy = (g.b >> 16) * a.stride + (ky - org) * dil;
+        const int vx = (g.b & 0xffff) * a.stride + (kx - org) * dil;
         if (vy < 0 || vx < 0 || vy >= a.Hin * a.up || vx >= a.Win * a.up) return nullptr;
         const int iy = (a.up == 2) ? (vy >> 1) : vy;
         const int ix = (a.up == 2) ? (vx >> 1) : vx;
@@ -326,6 +327,9 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
                     } else if (a.act == MOFA_ACT_RELU) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    } else if (a.act == MOFA_ACT_GELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
                     }
                 }
                 if (m < a.M && c4) {
@@ -573,12 +577,13 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (!a || !a->x || !a->w || !a->out) return MOFA_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->Cin <= 0) return MOFA_EINVAL;
     if (a->Cin % 64 != 0 || a->N % 4 != 0) return MOFA_EINVAL;
-    if (a->mode < 0 || a->mode > 2) return MOFA_EINVAL;
+    if (a->mode < 0 || a->mode > 2 || a->act < 0 || a->act > MOFA_ACT_GELU) return MOFA_EINVAL;
     if (a->mode == MOFA_MODE_CONV3X3) {
         if (a->Hin <= 0 || a->Win <= 0 || a->Hout <= 0 || a->Wout <= 0) return MOFA_EINVAL;
         if ((a->stride != 1 && a->stride != 2) || (a->up != 1 && a->up != 2)) return MOFA_EINVAL;
         if (a->ksize != 0 && a->ksize != 1 && a->ksize != 3 && a->ksize != 5 && a->ksize != 7) return MOFA_EINVAL;
         if (a->dil < 0 || (a->dil > 1 && a->up != 1)) return MOFA_EINVAL;
+        if (a->pad != MOFA_PAD_SAME && a->pad != MOFA_PAD_TRAILING) return MOFA_EINVAL;
         if (a->M % (a->Hout * a->Wout) != 0 || a->Hout > 65535 || a->Wout > 65535) return MOFA_EINVAL;
     }
     if (a->mode == MOFA_MODE_CONVT3 && (a->T < 0 || a->HW <= 0 || (a->T > 0 && a->M % (a->T * a->HW) != 0)))

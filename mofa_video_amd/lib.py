@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmofa_hip.so")
 
 MODE_PLAIN, MODE_CONV3X3, MODE_CONVT3 = 0, 1, 2
-ACT_NONE, ACT_SILU, ACT_GEGLU_PAIR, ACT_RELU = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_GEGLU_PAIR, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4
+PAD_SAME, PAD_TRAILING = 0, 1
 
 
 class IgemmArgs(C.Structure):
@@ -30,7 +31,7 @@ class IgemmArgs(C.Structure):
         ("rv_div", C.c_int32), ("rv_mul", C.c_int32), ("rv_mod_in", C.c_int32), ("rv_mod_out", C.c_int32),
         ("act", C.c_int32),
         ("s_acc", C.c_float), ("s1", C.c_float), ("s2", C.c_float),
-        ("dil", C.c_int32),
+        ("dil", C.c_int32), ("pad", C.c_int32),
     ]
 
 
@@ -75,6 +76,9 @@ PROTOTYPES = {
     "mofa_resize_bilinear_ac_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mofa_resize_bilinear_ac_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "mofa_flow_expectation_f16": [_P, _P, _I, _I, _I, _I, _F, _P],
+    "mofa_filter1d_reflect_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mofa_resize_bicubic_ac_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "mofa_patchify_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_frames_postprocess_f32": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_flow_to_image_ws_bytes": [_I, _I],
     "mofa_flow_to_image_u8": [_P, _P, _I, _I, _P, _P],

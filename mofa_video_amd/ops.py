@@ -74,22 +74,29 @@ def _chk(t, dtype):
 
 class ConvGeom:
     """Geometry of an implicit-GEMM launch."""
-    __slots__ = ("mode", "Hin", "Win", "Hout", "Wout", "stride", "up", "T", "HW", "ksize", "dil")
+    __slots__ = ("mode", "Hin", "Win", "Hout", "Wout", "stride", "up", "T", "HW", "ksize", "dil", "pad")
 
-    def __init__(self, mode=L.MODE_PLAIN, Hin=0, Win=0, Hout=0, Wout=0, stride=1, up=1, T=0, HW=0, ksize=3, dil=1):
+    def __init__(self, mode=L.MODE_PLAIN, Hin=0, Win=0, Hout=0, Wout=0, stride=1, up=1, T=0, HW=0, ksize=3, dil=1,
+                 pad=L.PAD_SAME):
         self.mode, self.Hin, self.Win, self.Hout, self.Wout = mode, Hin, Win, Hout, Wout
-        self.stride, self.up, self.T, self.HW, self.ksize, self.dil = stride, up, T, HW, ksize, dil
+        self.stride, self.up, self.T, self.HW, self.ksize, self.dil, self.pad = stride, up, T, HW, ksize, dil, pad
 
 
 PLAIN = ConvGeom()
 
 
-def conv3x3_geom(H, W, stride=1, up=1, ksize=3, dil=1):
-    """k x k convolution (k = 1, 3, 5, 7) with dilation dil and padding dil * (k // 2)"""
+def conv3x3_geom(H, W, stride=1, up=1, ksize=3, dil=1, pad=L.PAD_SAME):
+    """k x k convolution (k = 1, 3, 5, 7) with dilation dil and padding dil * (k // 2) on every side (PAD_SAME) or only
+    after the last row / column (PAD_TRAILING: diffusers Downsample2D(padding=0), F.pad(x, (0, 1, 0, 1)) for k = 3)"""
     Hv, Wv = H * up, W * up
-    Ho = (Hv - 1) // stride + 1
-    Wo = (Wv - 1) // stride + 1
-    return ConvGeom(L.MODE_CONV3X3, H, W, Ho, Wo, stride, up, ksize=ksize, dil=dil)
+    if pad == L.PAD_TRAILING:
+        span = dil * (ksize - 1) - dil * (ksize // 2)            # taps beyond the first that must fit without padding
+        Ho = (Hv - 1 - span) // stride + 1
+        Wo = (Wv - 1 - span) // stride + 1
+    else:
+        Ho = (Hv - 1) // stride + 1
+        Wo = (Wv - 1) // stride + 1
+    return ConvGeom(L.MODE_CONV3X3, H, W, Ho, Wo, stride, up, ksize=ksize, dil=dil, pad=pad)
 
 
 def convt3_geom(T, HW):
@@ -140,6 +147,7 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up = geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up
     a.ksize = geom.ksize
     a.dil = geom.dil
+    a.pad = geom.pad
     a.T, a.HW = geom.T, geom.HW
     a.rv_div, a.rv_mul, a.rv_mod_in, a.rv_mod_out = rv
     a.act = act
@@ -517,4 +525,40 @@ def flow_expectation(logits, nimg, H, W, nbins, fmax):
     out = torch.empty((nimg, 2, H, W), dtype=F32, device=logits.device)
     L.check(lib.mofa_flow_expectation_f16(L.ptr(logits), L.ptr(out), nimg, H * W, _ld(logits), nbins, float(fmax), L.stream_ptr()),
             "mofa_flow_expectation_f16")
+    return out
+
+
+# ---- image conditioning front end -------------------------------------------------------------
+def filter1d_reflect(x, taps, axis):
+    """x fp32 [..., H, W]; taps fp32 [k] on the device; axis 1 = along W, 0 = along H (pipeline.py:587-610 _filter2d)"""
+    lib = L.load()
+    _chk(x, F32); _chk(taps, F32)
+    assert x.is_contiguous() and taps.is_contiguous() and x.dim() >= 2
+    H, W = x.shape[-2:]
+    out = torch.empty_like(x)
+    L.check(lib.mofa_filter1d_reflect_f32(L.ptr(x), L.ptr(out), L.ptr(taps), x.numel() // (H * W), H, W, taps.numel(), axis,
+                                          L.stream_ptr()), "mofa_filter1d_reflect_f32")
+    return out
+
+
+def resize_bicubic_ac(x, Ho, Wo):
+    """F.interpolate(x, (Ho, Wo), mode="bicubic", align_corners=True) on fp32 [..., H, W]"""
+    lib = L.load()
+    _chk(x, F32)
+    assert x.is_contiguous() and x.dim() >= 2
+    H, W = x.shape[-2:]
+    out = torch.empty((*x.shape[:-2], Ho, Wo), dtype=F32, device=x.device)
+    L.check(lib.mofa_resize_bicubic_ac_f32(L.ptr(x), L.ptr(out), x.numel() // (H * W), H, W, Ho, Wo, L.stream_ptr()),
+            "mofa_resize_bicubic_ac_f32")
+    return out
+
+
+def patchify(x, p, ld):
+    """fp32 [n, C, H, W] -> fp16 [n*(H/p)*(W/p), ld] rows of C*p*p patch values (+ zero columns up to ld)"""
+    lib = L.load()
+    _chk(x, F32)
+    assert x.is_contiguous() and x.dim() == 4
+    n, Cc, H, W = x.shape
+    out = torch.empty((n * (H // p) * (W // p), ld), dtype=F16, device=x.device)
+    L.check(lib.mofa_patchify_f16(L.ptr(x), L.ptr(out), n, Cc, H, W, p, ld, L.stream_ptr()), "mofa_patchify_f16")
     return out

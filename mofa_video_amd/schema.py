@@ -211,6 +211,68 @@ def vae_decoder_schema(block_out_channels=(128, 256, 512, 512), layers_per_block
     return d
 
 
+def _resblock2d(d, p, cin, cout):
+    _norm(d, p + ".norm1", cin)
+    _conv(d, p + ".conv1", cout, cin, 3, 3)
+    _norm(d, p + ".norm2", cout)
+    _conv(d, p + ".conv2", cout, cout, 3, 3)
+    if cin != cout:
+        _conv(d, p + ".conv_shortcut", cout, cin, 1, 1)
+
+
+def vae_encoder_schema(block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, in_channels=3):
+    """``encoder.*`` + ``quant_conv.*`` of AutoencoderKLTemporalDecoder (diffusers models/vae.py Encoder: DownEncoderBlock2D
+    x4, UNetMidBlock2D with one 1-head attention, double_z conv_out); 34 163 664 parameters at the SVD configuration."""
+    d = {}
+    _conv(d, "encoder.conv_in", block_out_channels[0], in_channels, 3, 3)
+    c = block_out_channels[0]
+    for i, co in enumerate(block_out_channels):
+        for j in range(layers_per_block):
+            _resblock2d(d, f"encoder.down_blocks.{i}.resnets.{j}", c if j == 0 else co, co)
+        if i != len(block_out_channels) - 1:
+            _conv(d, f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co, 3, 3)
+        c = co
+    for j in range(2):
+        _resblock2d(d, f"encoder.mid_block.resnets.{j}", c, c)
+    a = "encoder.mid_block.attentions.0"
+    _norm(d, a + ".group_norm", c)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        _lin(d, f"{a}.{n}", c, c)
+    _norm(d, "encoder.conv_norm_out", c)
+    _conv(d, "encoder.conv_out", 2 * latent_channels, c, 3, 3)
+    _conv(d, "quant_conv", 2 * latent_channels, 2 * latent_channels, 1, 1)
+    return d
+
+
+CLIP_VIT_H = dict(hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=16, image_size=224,
+                  patch_size=14, projection_dim=1024, layer_norm_eps=1e-5)
+
+
+def clip_vision_schema(config=None):
+    """transformers CLIPVisionModelWithProjection ``state_dict`` (the reference's ``image_encoder``, run_gradio.py:98-100;
+    SVD ships the OpenCLIP ViT-H/14 tower)."""
+    c = dict(CLIP_VIT_H)
+    c.update(config or {})
+    h, p = c["hidden_size"], c["patch_size"]
+    d = {}
+    v = "vision_model."
+    d[v + "embeddings.class_embedding"] = (h,)
+    d[v + "embeddings.patch_embedding.weight"] = (h, 3, p, p)
+    d[v + "embeddings.position_embedding.weight"] = ((c["image_size"] // p) ** 2 + 1, h)
+    _norm(d, v + "pre_layrnorm", h)                                  # (sic) transformers' spelling
+    for i in range(c["num_hidden_layers"]):
+        q = f"{v}encoder.layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            _lin(d, q + "self_attn." + n, h, h)
+        _norm(d, q + "layer_norm1", h)
+        _lin(d, q + "mlp.fc1", c["intermediate_size"], h)
+        _lin(d, q + "mlp.fc2", h, c["intermediate_size"])
+        _norm(d, q + "layer_norm2", h)
+    _norm(d, v + "post_layernorm", h)
+    d["visual_projection.weight"] = (c["projection_dim"], h)
+    return d
+
+
 def _bn(d, p, c):
     d[p + ".weight"] = (c,)
     d[p + ".bias"] = (c,)
