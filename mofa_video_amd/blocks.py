@@ -77,17 +77,17 @@ class Linear:
 
 
 class Conv3x3:
-    def __init__(self, s, stride=1, up=1, pad_n=False):
+    def __init__(self, s, stride=1, up=1, pad_n=False, pad=L.PAD_SAME):
         w, b = s.get("weight"), s.get("bias")
         self.n_real = w.shape[0]
         if pad_n:
             w, b = pad_rows(w), pad_rows(b)
         self.w = s.dev(pack_conv3x3(w))
         self.b = s.dev(f32(b))
-        self.stride, self.up = stride, up
+        self.stride, self.up, self.pad = stride, up, pad
 
     def __call__(self, x, H, W, **kw):
-        return ops.igemm(x, self.w, self.b, geom=ops.conv3x3_geom(H, W, self.stride, self.up), **kw)
+        return ops.igemm(x, self.w, self.b, geom=ops.conv3x3_geom(H, W, self.stride, self.up, pad=self.pad), **kw)
 
 
 class ConvT3:

@@ -25,7 +25,7 @@ from typing import Callable, Dict, List, Optional, Union
 import numpy as np
 import torch
 
-from . import ops
+from . import frontend, ops
 from .blocks import Ctx
 from .output import tensor2vid
 from .vae import decode_latents
@@ -62,7 +62,7 @@ class FlowControlNetPipeline:
         self.parallel = parallel
 
     def check_inputs(self, image, height, width):                      # pipeline.py:222-234
-        if image is not None and not torch.is_tensor(image) and not isinstance(image, list):
+        if image is not None and not torch.is_tensor(image) and not isinstance(image, list) and not hasattr(image, "convert"):
             raise ValueError("`image` has to be of type `torch.FloatTensor` or `PIL.Image.Image` or "
                              f"`List[PIL.Image.Image]` but is {type(image)}")
         if height % 8 != 0 or width % 8 != 0:
@@ -75,16 +75,30 @@ class FlowControlNetPipeline:
                                   device=generator.device if generator is not None else "cpu")
         return latents.to(self.device, torch.float32) * self.scheduler.init_noise_sigma   # :272
 
-    def _conditioning(self, image, image_embeddings, image_latents):
+    def _encode_image(self, image01):                                   # pipeline.py:114-139
+        if self.image_encoder is None:
+            raise ValueError("no image_encoder: pass image_embeddings=... or build the pipeline with one")
+        return frontend.encode_image(self.image_encoder, image01)
+
+    def _encode_vae_image(self, image01, noise_aug_strength, generator):  # pipeline.py:141-162, :338-352
+        if self.vae is None or getattr(self.vae, "encoder", None) is None:
+            raise ValueError("the VAE has no encoder weights: pass image_latents=... or load encoder.* / quant_conv.*")
+        return frontend.encode_vae_image(self.vae, image01, noise_aug_strength, generator)
+
+    def _conditioning(self, image, image_embeddings, image_latents, height=None, width=None, noise_aug_strength=0.02,
+                      generator=None):
+        """image: PIL / tensor in [0, 1] (what the reference's numpy_to_pt yields); either half can be supplied
+        precomputed through the ``image_embeddings`` / ``image_latents`` extensions."""
         dev = self.device
+        image01 = None
+        if image_embeddings is None or image_latents is None:
+            if image is None:
+                raise ValueError("pass `image`, or both image_embeddings=... and image_latents=...")
+            image01 = frontend.image_to_01(image, height, width, dev)
         if image_embeddings is None:
-            if self.image_encoder is None:
-                raise ValueError("pass image_embeddings=... (CLIP runs outside the hot path)")
-            image_embeddings = self.image_encoder(image)
+            image_embeddings = self._encode_image(image01)
         if image_latents is None:
-            if self.vae is None or not hasattr(self.vae, "encode"):
-                raise ValueError("pass image_latents=... (VAE encode runs outside the hot path)")
-            image_latents = self.vae.encode(image)
+            image_latents = self._encode_vae_image(image01, noise_aug_strength, generator)
         emb = image_embeddings.to(dev, torch.float32).reshape(-1, 1, image_embeddings.shape[-1])
         if emb.shape[0] == 1:                                             # :133-139 uncond = zeros
             emb = torch.cat([torch.zeros_like(emb), emb])
@@ -116,7 +130,7 @@ class FlowControlNetPipeline:
         T = num_frames
 
         # 3./4. image conditioning (computed before the hot path)
-        emb, il = self._conditioning(image, image_embeddings, image_latents)
+        emb, il = self._conditioning(image, image_embeddings, image_latents, height, width, noise_aug_strength, generator)
 
         # 4./5. schedule + latents (every rank prepares the full clip's latents; it keeps its own frames below)
         sch.set_timesteps(num_inference_steps)
@@ -215,7 +229,7 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
         decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else T
         self.check_inputs(image, height, width)
         h, w = height // 8, width // 8
-        emb, il = self._conditioning(image, image_embeddings, image_latents)
+        emb, il = self._conditioning(image, image_embeddings, image_latents, height, width, noise_aug_strength, generator)
         sch.set_timesteps(num_inference_steps)
         timesteps = sch.timesteps
         lat = self.prepare_latents(1, T, unet.config.in_channels, height, width, generator, latents).reshape(T, 4, h, w).contiguous()
@@ -317,7 +331,7 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else N
         self.check_inputs(image, height, width)
         h, w = height // 8, width // 8
-        emb, il = self._conditioning(image, image_embeddings, image_latents)
+        emb, il = self._conditioning(image, image_embeddings, image_latents, height, width, noise_aug_strength, generator)
         sch.set_timesteps(num_inference_steps)
         timesteps = sch.timesteps
         lat = self.prepare_latents(1, N, unet.config.in_channels, height, width, generator, latents).reshape(N, 4, h, w).contiguous()

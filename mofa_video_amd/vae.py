@@ -1,8 +1,9 @@
-"""MI355X host mirror of ``AutoencoderKLTemporalDecoder.decode`` (diffusers==0.24.0
-models/autoencoder_kl_temporal_decoder.py), called by the reference at
+"""MI355X host mirror of ``AutoencoderKLTemporalDecoder`` (diffusers==0.24.0
+models/autoencoder_kl_temporal_decoder.py): ``decode``, called by the reference at
 MOFA-Video-Traj/pipeline/pipeline.py:194-220 (``decode_latents``: /scaling_factor, chunks of
-``decode_chunk_size`` frames, each chunk decoded independently).  ``state_dict`` keys are the diffusers
-``decoder.*`` names.  The encoder half runs once per clip before the hot path and is out of scope.
+``decode_chunk_size`` frames, each chunk decoded independently), and ``encode(x).latent_dist.mode()``, called once per
+clip at pipeline.py:141-162 (built when the state_dict holds ``encoder.*``).  ``state_dict`` keys are the
+diffusers ``decoder.*`` / ``encoder.*`` / ``quant_conv.*`` names.
 """
 import math
 
@@ -11,6 +12,7 @@ import torch
 from . import lib as L
 from . import ops
 from .blocks import Conv3x3, ConvT3, Ctx, GroupNorm, Linear, SpatioTemporalResBlock, Sub
+from .weights import f32, pack_conv3x3
 
 
 def _res(s):
@@ -40,6 +42,76 @@ class _MidAttention:
             ops.softmax_rows_(p)
             ops.igemm(p, vt[f * Cc:(f + 1) * Cc], out=o[rows])           # P V
         return self.to_out(o, r1=x, s1=1.0)
+
+
+class _ResnetBlock2D:
+    """diffusers ResnetBlock2D without time embedding (VAE encoder): GN-SiLU-conv, GN-SiLU-conv (+ 1x1 shortcut)."""
+
+    def __init__(self, s, eps=1e-6):
+        self.norm1, self.norm2 = GroupNorm(s.sub("norm1"), eps), GroupNorm(s.sub("norm2"), eps)
+        self.conv1, self.conv2 = Conv3x3(s.sub("conv1")), Conv3x3(s.sub("conv2"))
+        self.shortcut = Linear(s.sub("conv_shortcut")) if s.has("conv_shortcut.weight") else None
+
+    def __call__(self, x, n, H, W):
+        h = self.conv1(self.norm1(x, n, H * W, silu=True), H, W)
+        h = self.norm2(h, n, H * W, silu=True)
+        xs = self.shortcut(x) if self.shortcut is not None else x
+        return self.conv2(h, H, W, r1=xs, s1=1.0)
+
+
+class Encoder:
+    """diffusers models/vae.py Encoder (DownEncoderBlock2D x N, UNetMidBlock2D, GN-SiLU-conv_out) with ``quant_conv``
+    folded into ``conv_out`` (both linear, nothing between them) and only the mean rows kept: the reference reads
+    ``latent_dist.mode()`` = the first ``latent_channels`` of the moments (pipeline.py:150)."""
+
+    def __init__(self, s, quant, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4):
+        self.conv_in = Conv3x3(s.sub("conv_in"))
+        self.in_ld = self.conv_in.w.shape[1] // 9
+        self.down = []
+        n = len(block_out_channels)
+        for i in range(n):
+            b = s.sub(f"down_blocks.{i}")
+            res = [_ResnetBlock2D(b.sub(f"resnets.{j}")) for j in range(layers_per_block)]
+            # Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) then a stride-2 conv = trailing-only padding
+            down = Conv3x3(b.sub("downsamplers.0.conv"), stride=2, pad=L.PAD_TRAILING) if i != n - 1 else None
+            self.down.append((res, down))
+        m = s.sub("mid_block")
+        self.mid_res = [_ResnetBlock2D(m.sub(f"resnets.{j}")) for j in range(2)]
+        self.mid_attn = _MidAttention(m.sub("attentions.0"))
+        self.conv_norm_out = GroupNorm(s.sub("conv_norm_out"), 1e-6)
+        wc, bc = s.get("conv_out.weight").float(), s.get("conv_out.bias").float()            # [2z, C, 3, 3]
+        wq, bq = quant.get("weight").float().flatten(1), quant.get("bias").float()            # [2z, 2z]
+        w = torch.einsum("om,mcyx->ocyx", wq, wc)[:latent_channels]
+        b = (wq @ bc + bq)[:latent_channels]
+        self.out_w, self.out_b = s.dev(pack_conv3x3(w)), s.dev(f32(b))
+        self.latent_channels = latent_channels
+
+    def __call__(self, x, n, H, W):
+        x = self.conv_in(x, H, W)
+        for res, down in self.down:
+            for r in res:
+                x = r(x, n, H, W)
+            if down is not None:
+                x = down(x, H, W)
+                H, W = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+        x = self.mid_res[0](x, n, H, W)
+        x = self.mid_attn(x, n, H * W)
+        x = self.mid_res[1](x, n, H, W)
+        x = self.conv_norm_out(x, n, H * W, silu=True)
+        return ops.igemm(x, self.out_w, self.out_b, geom=ops.conv3x3_geom(H, W)), H, W      # [n*H*W, z] mean
+
+
+class _Posterior:
+    def __init__(self, mean):
+        self.mean = mean
+
+    def mode(self):
+        return self.mean
+
+
+class _EncoderOutput:
+    def __init__(self, latent_dist):
+        self.latent_dist = latent_dist
 
 
 class TemporalDecoder:
@@ -92,6 +164,20 @@ class AutoencoderKLTemporalDecoder:
         self.dtype = torch.float16
         self.decoder = TemporalDecoder(Sub(state_dict, "decoder.", device), tuple(cfg["block_out_channels"]),
                                        cfg["layers_per_block"])
+        self.encoder = None
+        if "encoder.conv_in.weight" in state_dict:
+            self.encoder = Encoder(Sub(state_dict, "encoder.", device), Sub(state_dict, "quant_conv.", device),
+                                   tuple(cfg["block_out_channels"]), cfg["layers_per_block"], cfg["latent_channels"])
+
+    def encode(self, x):
+        """x fp32 [n, 3, H, W] in [-1, 1] -> ``.latent_dist.mode()`` fp32 [n, 4, H/8, W/8] (the reference upcasts the
+        VAE to fp32 for this call, pipeline.py:343-352; here fp16 storage with fp32 accumulation)"""
+        if self.encoder is None:
+            raise ValueError("this AutoencoderKLTemporalDecoder was built from a state_dict without encoder.* weights")
+        n, c, H, W = x.shape
+        xt = ops.nchw_to_tokens(x.to(self.device, torch.float32).contiguous(), ld=self.encoder.in_ld)
+        y, h, w = self.encoder(xt, n, H, W)
+        return _EncoderOutput(_Posterior(ops.tokens_to_nchw(y, n, self.encoder.latent_channels, h, w)))
 
     @classmethod
     def from_module(cls, module, device="cuda"):

@@ -1,0 +1,196 @@
+"""GPU parity of the image-conditioning front end through the C ABI: antialiased resize against the fixture
+written by the reference's own functions and against the oracle at BASELINE's 576x1024; CLIP vision tower against the
+fixture written by transformers' class (2 layers, head dim 80) and against the oracle at the full ViT-H/14 shape; VAE
+encoder against the oracle at a reduced and at the full 576x1024 configuration; the new igemm options on their own.
+
+Stated tolerances: fp32 kernels (blur, bicubic) <= 5e-6 absolute on [0, 1] data; patchify bit-exact; fp16-storage paths
+(igemm, CLIP, VAE encoder) relative L2 <= 1e-2 against the fp32 oracle."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_l2
+from mofa_video_amd import schema
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return torch.load(os.path.join(GD, "reference_golden_frontend.pt"), weights_only=False)
+
+
+def test_resize_matches_reference_fixture(golden):
+    from mofa_video_amd.frontend import _resize_with_antialiasing
+    for name, c in golden["resize"].items():
+        out = _resize_with_antialiasing(c["x"].to(DEV), c["size"]).cpu()
+        assert tuple(out.shape) == tuple(c["out"].shape), name
+        e = (out - c["out"]).abs().max().item()
+        print(f"resize {name}: max abs err {e:.2e}")
+        assert e < 5e-6, (name, e)
+
+
+def test_resize_fullsize_matches_oracle():
+    from mofa_video_amd.frontend import _resize_with_antialiasing
+    from oracle.frontend import resize_with_antialiasing
+    x = torch.rand(1, 3, 576, 1024, generator=torch.Generator().manual_seed(2))
+    ref = resize_with_antialiasing(x, (224, 224))
+    out = _resize_with_antialiasing(x.to(DEV), (224, 224))
+    assert torch.equal(out, _resize_with_antialiasing(x.to(DEV), (224, 224)))
+    assert (out.cpu() - ref).abs().max().item() < 5e-6
+
+
+def test_patchify_bit_exact():
+    from mofa_video_amd import ops
+    x = torch.randn(2, 3, 28, 42, generator=torch.Generator().manual_seed(3))
+    got = ops.patchify(x.to(DEV), 14, 640).cpu()
+    ref = F.unfold(x, kernel_size=14, stride=14).transpose(1, 2).reshape(2 * 2 * 3, 588).to(torch.float16)
+    assert torch.equal(got[:, :588], ref) and torch.equal(got[:, 588:], torch.zeros(12, 52, dtype=torch.float16))
+
+
+@pytest.mark.parametrize("H,W", [(16, 24), (17, 23)])
+def test_igemm_trailing_pad_stride2(H, W):
+    """diffusers Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) + stride-2 3x3 conv"""
+    from mofa_video_amd import lib as L, ops
+    from mofa_video_amd.weights import pack_conv3x3
+    g = torch.Generator().manual_seed(4)
+    n, Cin, N = 2, 64, 96
+    x = torch.randn(n, Cin, H, W, generator=g).half()
+    w = (torch.randn(N, Cin, 3, 3, generator=g) / 24).half()
+    b = torch.randn(N, generator=g)
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b, stride=2)
+    geom = ops.conv3x3_geom(H, W, stride=2, pad=L.PAD_TRAILING)
+    assert (geom.Hout, geom.Wout) == tuple(ref.shape[-2:])
+    xt = x.permute(0, 2, 3, 1).reshape(n * H * W, Cin).contiguous().to(DEV)
+    got = ops.igemm(xt, pack_conv3x3(w).to(DEV), b.to(DEV), geom=geom)
+    e = rel_l2(got, ref.permute(0, 2, 3, 1).reshape(-1, N))
+    assert e < 2e-3, e
+
+
+def test_igemm_gelu_epilogue():
+    from mofa_video_amd import lib as L, ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(257, 320, generator=g).half()
+    w = (torch.randn(640, 320, generator=g) / 8).half()
+    b = torch.randn(640, generator=g)
+    r = torch.randn(257, 640, generator=g).half()
+    ref = F.gelu(x.float() @ w.float().T + b)
+    got = ops.igemm(x.to(DEV), w.to(DEV), b.to(DEV), act=L.ACT_GELU)
+    assert (got.float().cpu() - ref).abs().max().item() < 4e-3
+    assert rel_l2(got, ref) < 2e-3
+    ref2 = F.gelu(x.float() @ w.float().T + b + 0.5 * r.float())        # activation after the residual, like SiLU / ReLU
+    got2 = ops.igemm(x.to(DEV), w.to(DEV), b.to(DEV), r1=r.to(DEV), s1=0.5, act=L.ACT_GELU)
+    assert rel_l2(got2, ref2) < 2e-3
+
+
+def test_clip_encode_image_matches_transformers_fixture(golden):
+    """2 layers, hidden 320, 4 heads of dim 80 (the ViT-H head dim: exercises the 128-column head slots and the
+    masked key padding 257 -> 264); fixture = reference _encode_image on transformers' CLIPVisionModelWithProjection"""
+    from mofa_video_amd.clip import CLIPVisionModelWithProjection
+    from mofa_video_amd.frontend import _resize_with_antialiasing, encode_image
+    G = golden["encode_image"]
+    sd = schema.synthetic_state_dict(schema.clip_vision_schema(G["cfg"]), seed=G["seed"], dtype=torch.float32)
+    enc = CLIPVisionModelWithProjection(sd, G["cfg"], DEV)
+    emb = encode_image(enc, G["image"].to(DEV))
+    assert tuple(emb.shape) == tuple(G["image_embeddings"].shape)
+    assert torch.equal(emb[0].cpu(), torch.zeros_like(G["image_embeddings"][0]))
+    e = rel_l2(emb[1], G["image_embeddings"][1])
+    x = enc.hidden_states(_resize_with_antialiasing(G["image"].to(DEV), (224, 224)))
+    e0, e200 = rel_l2(x[0], G["last_hidden_state_cls"][0]), rel_l2(x[200], G["last_hidden_state_tok200"][0])
+    print(f"CLIP (2 layers): image_embeds rel-L2 {e:.3e}, last hidden CLS {e0:.3e}, token 200 {e200:.3e}")
+    assert e < 1e-2 and e0 < 1e-2 and e200 < 1e-2, (e, e0, e200)
+    assert torch.equal(emb, encode_image(enc, G["image"].to(DEV)))      # deterministic
+
+
+def test_clip_vit_h_matches_oracle():
+    """the full ViT-H/14 tower the SVD checkpoint ships (32 layers, 16 x 80), seeded weights, against the fp32 oracle"""
+    from mofa_video_amd.clip import CLIPVisionModelWithProjection
+    from oracle.clip import CLIPVisionModelWithProjection as Oracle
+    sd = schema.synthetic_state_dict(schema.clip_vision_schema(), seed=33)          # fp16-valued
+    ref_model = Oracle().eval()
+    ref_model.load_state_dict({k: v.float() for k, v in sd.items()})
+    pv = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+    ref = ref_model(pv).image_embeds
+    enc = CLIPVisionModelWithProjection(sd, None, DEV)
+    got = enc(pv.to(DEV)).image_embeds
+    assert tuple(got.shape) == (1, 1024) and got.dtype == torch.float16
+    e = rel_l2(got, ref)
+    print(f"CLIP ViT-H/14: image_embeds rel-L2 {e:.3e}")
+    assert e < 1e-2, e
+
+
+def _vae_pair(cfg, seed):
+    from mofa_video_amd.vae import AutoencoderKLTemporalDecoder
+    from oracle.vae import AutoencoderKLTemporalDecoder as Oracle
+    sd = schema.synthetic_state_dict(schema.vae_decoder_schema(**cfg), seed=seed)
+    sd.update(schema.synthetic_state_dict(schema.vae_encoder_schema(**cfg), seed=seed + 1))
+    ref = Oracle(with_encoder=True, **cfg).eval()
+    ref.load_state_dict({k: v.float() for k, v in sd.items()})
+    return ref, AutoencoderKLTemporalDecoder(sd, cfg, DEV)
+
+
+def test_vae_encoder_small_matches_oracle():
+    from mofa_video_amd.frontend import encode_vae_image
+    from oracle.frontend import encode_vae_image as oracle_encode
+    ref, vae = _vae_pair(dict(block_out_channels=(64, 64, 128, 128)), seed=40)
+    g = torch.Generator().manual_seed(8)
+    img = torch.rand(1, 3, 128, 192, generator=g)
+    noise = torch.randn(1, 3, 128, 192, generator=g)
+    want = oracle_encode(ref, img * 2 - 1, noise)
+    got = encode_vae_image(vae, img.to(DEV), noise=noise)
+    assert tuple(got.shape) == tuple(want.shape) == (2, 4, 16, 24)
+    assert torch.equal(got[0].cpu(), torch.zeros(4, 16, 24))
+    e = rel_l2(got[1], want[1])
+    print(f"VAE encoder (reduced): latents rel-L2 {e:.3e}")
+    assert e < 1e-2, e
+    # seeded draw: same generator state -> same noise as the reference's randn_tensor on the CPU generator
+    a = encode_vae_image(vae, img.to(DEV), generator=torch.Generator().manual_seed(9))
+    b = encode_vae_image(vae, img.to(DEV), noise=torch.randn(1, 3, 128, 192, generator=torch.Generator().manual_seed(9)))
+    assert torch.equal(a, b)
+
+
+def test_vae_encoder_fullsize_matches_oracle():
+    """the SVD VAE encoder (128, 256, 512, 512) at BASELINE's 576x1024"""
+    ref, vae = _vae_pair({}, seed=50)
+    img = torch.rand(1, 3, 576, 1024, generator=torch.Generator().manual_seed(10)) * 2 - 1
+    with torch.no_grad():
+        want = ref.encode(img).latent_dist.mode()
+    got = vae.encode(img.to(DEV)).latent_dist.mode()
+    assert tuple(got.shape) == tuple(want.shape) == (1, 4, 72, 128)
+    assert torch.isfinite(got).all()
+    e = rel_l2(got, want)
+    print(f"VAE encoder 576x1024: latents rel-L2 {e:.3e}")
+    assert e < 1e-2, e
+    assert torch.equal(got, vae.encode(img.to(DEV)).latent_dist.mode())
+
+
+def test_pipeline_conditioning_from_image():
+    """FlowControlNetPipeline._conditioning(image=...) = oracle encode_image / encode_vae_image (pipeline.py:330-352)"""
+    from mofa_video_amd.clip import CLIPVisionModelWithProjection
+    from mofa_video_amd.pipeline import FlowControlNetPipeline
+    from oracle.clip import CLIPVisionModelWithProjection as OracleClip
+    from oracle.frontend import encode_image, encode_vae_image
+    ccfg = dict(hidden_size=320, intermediate_size=640, num_hidden_layers=2, num_attention_heads=4, projection_dim=128)
+    sdc = schema.synthetic_state_dict(schema.clip_vision_schema(ccfg), seed=60)
+    oc = OracleClip(ccfg).eval()
+    oc.load_state_dict({k: v.float() for k, v in sdc.items()})
+    ref_vae, vae = _vae_pair(dict(block_out_channels=(64, 64, 128, 128)), seed=61)
+    H, W = 128, 192
+    img = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(12))
+    pipe = FlowControlNetPipeline(vae=vae, image_encoder=CLIPVisionModelWithProjection(sdc, ccfg, DEV),
+                                  unet=type("U", (), {"device": torch.device(DEV)})())
+    emb, il = pipe._conditioning(img, None, None, H, W, 0.02, torch.Generator().manual_seed(13))
+    noise = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(13))
+    want_emb = encode_image(oc, img)
+    want_il = encode_vae_image(ref_vae, img * 2 - 1, noise, 0.02)
+    assert tuple(emb.shape) == tuple(want_emb.shape) and tuple(il.shape) == tuple(want_il.shape)
+    assert rel_l2(emb, want_emb) < 1e-2 and rel_l2(il, want_il) < 1e-2
+    import numpy as np
+    from PIL import Image
+    pil = Image.fromarray((img[0].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8))
+    emb2, il2 = pipe._conditioning(pil, None, None, H, W, 0.02, torch.Generator().manual_seed(13))
+    assert rel_l2(emb2, want_emb) < 2e-2 and rel_l2(il2, want_il) < 2e-2        # 8-bit quantised copy of the same image
