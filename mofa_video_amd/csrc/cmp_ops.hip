@@ -61,7 +61,8 @@ extern "C" int mofa_pool2d_f16(const void* x, void* out, int nimg, int Hin, int 
 // align_corners=True source coordinate: dst * (in - 1) / (out - 1)   (0 when out == 1), as ATen computes it in fp32
 __device__ __forceinline__ void ac_coord(int d, int in, int out, int& i0, int& i1, float& f) {
     const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f;
-    const float s = scale * (float)d;
+    float s = scale * (float)d;
+    asm volatile("" : "+v"(s));   // keep s rounded: a fused scale*d - i0 would move f by up to an ulp of s (see frontend.hip)
     i0 = (int)s;
     i1 = i0 + (i0 < in - 1 ? 1 : 0);
     f = s - (float)i0;

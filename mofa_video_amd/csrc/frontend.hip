@@ -55,9 +55,12 @@ extern "C" int mofa_filter1d_reflect_f32(const float* x, float* out, const float
 // cubic convolution weights (Keys, A = -0.75) for the taps at floor(s) - 1 .. floor(s) + 2, s = o * (in-1)/(out-1) in fp32
 __device__ __forceinline__ void cubic_taps(const int o, const int nin, const int nout, int idx[4], float w[4]) {
     const float scale = nout > 1 ? (float)(nin - 1) / (float)(nout - 1) : 0.0f;
-    const float s = __fmul_rn(scale, (float)o);
+    float s = scale * (float)o;
+    // s must be rounded before t = s - floor(s) (ATen rounds it): hipcc would otherwise fuse scale*o - floor(s) into one
+    // fma, which moves t by up to an ulp of s (1.5e-5 at s = 255) -- seen as 1e-5 output error against the reference
+    asm volatile("" : "+v"(s));
     const float f = floorf(s);
-    const float t = fminf(fmaxf(__fsub_rn(s, f), 0.0f), 1.0f);
+    const float t = fminf(fmaxf(s - f, 0.0f), 1.0f);
     const int i0 = (int)f;
     const float A = -0.75f;
     const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;

@@ -3,7 +3,7 @@ written by the reference's own functions and against the oracle at BASELINE's 57
 fixture written by transformers' class (2 layers, head dim 80) and against the oracle at the full ViT-H/14 shape; VAE
 encoder against the oracle at a reduced and at the full 576x1024 configuration; the new igemm options on their own.
 
-Stated tolerances: fp32 kernels (blur, bicubic) <= 5e-6 absolute on [0, 1] data; patchify bit-exact; fp16-storage paths
+Stated tolerances: fp32 kernels (blur, bicubic) <= 2e-6 absolute on [0, 1] data; patchify bit-exact; fp16-storage paths
 (igemm, CLIP, VAE encoder) relative L2 <= 1e-2 against the fp32 oracle."""
 import os
 
@@ -31,7 +31,7 @@ def test_resize_matches_reference_fixture(golden):
         assert tuple(out.shape) == tuple(c["out"].shape), name
         e = (out - c["out"]).abs().max().item()
         print(f"resize {name}: max abs err {e:.2e}")
-        assert e < 5e-6, (name, e)
+        assert e < 2e-6, (name, e)
 
 
 def test_resize_fullsize_matches_oracle():
@@ -41,7 +41,7 @@ def test_resize_fullsize_matches_oracle():
     ref = resize_with_antialiasing(x, (224, 224))
     out = _resize_with_antialiasing(x.to(DEV), (224, 224))
     assert torch.equal(out, _resize_with_antialiasing(x.to(DEV), (224, 224)))
-    assert (out.cpu() - ref).abs().max().item() < 5e-6
+    assert (out.cpu() - ref).abs().max().item() < 2e-6
 
 
 def test_patchify_bit_exact():
@@ -111,8 +111,9 @@ def test_clip_vit_h_matches_oracle():
     from mofa_video_amd.clip import CLIPVisionModelWithProjection
     from oracle.clip import CLIPVisionModelWithProjection as Oracle
     sd = schema.synthetic_state_dict(schema.clip_vision_schema(), seed=33)          # fp16-valued
-    ref_model = Oracle().eval()
-    ref_model.load_state_dict({k: v.float() for k, v in sd.items()})
+    with torch.device("meta"):                                         # skip the 632 M-parameter random init
+        ref_model = Oracle().eval()
+    ref_model.load_state_dict({k: v.float() for k, v in sd.items()}, assign=True)
     pv = torch.rand(1, 3, 224, 224, generator=torch.Generator().manual_seed(6))
     ref = ref_model(pv).image_embeds
     enc = CLIPVisionModelWithProjection(sd, None, DEV)
