@@ -7,8 +7,10 @@ hint").
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one whole clip: adapter condition preparation + 25 denoise steps (ControlNet trunk + UNet + CFG/Euler)
-+ chunked temporal-VAE decode, on synthetic inputs already resident in HBM.  Weights are seeded random in the
+One "step" = one whole clip, the reference pipeline call from the conditioning image to the frames: image conditioning
+(antialiased resize + CLIP ViT-H/14 image encoder, noise augmentation + VAE encoder; once per clip, < 1 % of the time) +
+adapter condition preparation + 25 denoise steps (ControlNet trunk + UNet + CFG/Euler) + chunked temporal-VAE decode, on
+synthetic inputs already resident in HBM.  Weights are seeded random in the
 reference checkpoint layout (no checkpoints offline), fp16 storage / fp32 accumulate -- the reference's precision.
 N > 1 (one process per GPU): default ``--mode shard`` partitions ONE clip over the ranks -- 2-way CFG x N/2 frame
 shards with RCCL exchanges only at the temporal ops (mofa_video_amd/parallel.py; strong scaling) -- and
@@ -43,6 +45,7 @@ def synthetic_inputs(device, seed=42):
     il = torch.randn(1, 4, h, w, generator=g) / 0.18215
     emb = torch.randn(1, 1, 1024, generator=g)
     cond = torch.rand(1, 3, H, W, generator=g) * 2 - 1
+    image = cond * 0.5 + 0.5                                  # the conditioning image in [0, 1] (= the first frame)
     ys = torch.arange(H, dtype=torch.float32).view(H, 1)
     xs = torch.arange(W, dtype=torch.float32).view(1, W)
     sig = 0.15 * min(H, W)
@@ -53,32 +56,40 @@ def synthetic_inputs(device, seed=42):
         flow[0, i, 0] = bump * 64.0 * f
         flow[0, i, 1] = bump * 32.0 * f
     return {k: v.to(device) for k, v in dict(latents=lat, image_latents=il, image_embeddings=emb, cond=cond,
-                                             flow=flow).items()}
+                                             flow=flow, image=image).items()}
 
 
-def build_pipeline(device, seed=0):
+def build_pipeline(device, seed=0, frontend=False):
+    """frontend=True also builds the CLIP image encoder and the VAE encoder half (the once-per-clip conditioning)"""
     from mofa_video_amd import schema
     from mofa_video_amd.adapter import FlowControlNet
+    from mofa_video_amd.clip import CLIPVisionModelWithProjection
     from mofa_video_amd.pipeline import FlowControlNetPipeline
     from mofa_video_amd.scheduler import EulerDiscreteScheduler
     from mofa_video_amd.unet import UNetSpatioTemporalConditionControlNetModel
     from mofa_video_amd.vae import AutoencoderKLTemporalDecoder
     mods = []
-    for i, (cls, sch) in enumerate([(UNetSpatioTemporalConditionControlNetModel, schema.unet_schema()),
-                                    (FlowControlNet, schema.controlnet_schema()),
-                                    (AutoencoderKLTemporalDecoder, schema.vae_decoder_schema())]):
+    vae_schema = schema.vae_decoder_schema()
+    todo = [(UNetSpatioTemporalConditionControlNetModel, schema.unet_schema()), (FlowControlNet, schema.controlnet_schema()),
+            (AutoencoderKLTemporalDecoder, vae_schema)]
+    if frontend:
+        vae_schema.update(schema.vae_encoder_schema())
+        todo.append((CLIPVisionModelWithProjection, schema.clip_vision_schema()))
+    for i, (cls, sch) in enumerate(todo):
         sd = schema.synthetic_state_dict(sch, seed=seed + i, device=device)
         mods.append(cls(sd, None, device))
         del sd
         torch.cuda.empty_cache()
-    unet, cn, vae = mods
-    return FlowControlNetPipeline(vae=vae, unet=unet, controlnet=cn, scheduler=EulerDiscreteScheduler())
+    unet, cn, vae = mods[:3]
+    return FlowControlNetPipeline(vae=vae, image_encoder=mods[3] if frontend else None, unet=unet, controlnet=cn,
+                                  scheduler=EulerDiscreteScheduler())
 
 
 def run_clip(pipe, inp):
-    out = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=H, width=W, num_frames=T,
+    """the reference call (MOFA-Video-Traj/run_gradio.py:330-352 -> pipeline.py:293): image in, frames out"""
+    out = pipe(inp["image"], controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=H, width=W, num_frames=T,
                num_inference_steps=STEPS, decode_chunk_size=CHUNK, latents=inp["latents"], output_type="pt",
-               image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"])
+               generator=torch.Generator().manual_seed(1234))
     return out.frames
 
 
@@ -184,7 +195,7 @@ def main():
 
     from mofa_video_amd import lib, ops
     lib.load()                                              # fails loudly without the HIP library
-    pipe = build_pipeline(dev, seed=0)
+    pipe = build_pipeline(dev, seed=0, frontend=True)
     mode = args.mode if world > 1 else "single"
     mode_note = ""
     if mode == "shard":
@@ -236,12 +247,15 @@ def main():
         ach = ig["flops"] / ig["seconds"] / 1e12
         at = summ.get("attn_spatial_kernel")
         traffic = None       # HBM bytes per launch from the committed PMC passes (not collectable live)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01c_igemm_traffic.json")))
-            traffic = dict(hbm_bytes_per_launch=round(tj["hbm_bytes_per_launch"]), source="profiles/r01c_igemm_traffic.json "
-                           "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 x2 FETCH correction)")
-        except Exception:  # noqa: BLE001
-            pass
+        for tag in ("r01d", "r01c"):                                  # newest committed PMC summary (tools/profile_round.sh)
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_igemm_traffic.json")))
+                traffic = dict(hbm_bytes_per_launch=round(tj["hbm_bytes_per_launch"]),
+                               source=f"profiles/{tag}_igemm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                      "passes, gfx950 x2 FETCH correction)")
+                break
+            except Exception:  # noqa: BLE001
+                pass
         roofline = dict(kernel="igemm_f16_kernel", bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         launches_per_clip=ig["launches"] // max(args.steps, 1),
@@ -268,8 +282,8 @@ def main():
                                    "(chunk 8), single trajectory hint, SVD-XT UNet + MOFA-Adapter, CFG 1->3, "
                                    "seeded random weights in the reference checkpoint layout",
                        "num_frames": T, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
-                       "decode_chunk_size": CHUNK, "step_definition": "one whole clip (adapter prep + 25 denoise "
-                       "steps + VAE decode)", "parallelism": par_desc,
+                       "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
+                       "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
                        "output_finite": finite,
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOP * clips / dt / world, 1)},
             "roofline": roofline,

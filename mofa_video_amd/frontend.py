@@ -79,10 +79,12 @@ def encode_image(image_encoder, image01, do_classifier_free_guidance=True):
 def encode_vae_image(vae, image01, noise_aug_strength=0.02, generator=None, do_classifier_free_guidance=True, noise=None):
     """pipeline.py:338-352 + :141-162: x = 2*image - 1 (VaeImageProcessor.normalize), + noise_aug_strength * randn, VAE
     encoder mode, [zeros, latents].  ``noise`` overrides the draw (tests)."""
-    x = image01.to(torch.float32) * 2.0 - 1.0
+    img = image01.to(torch.float32).contiguous()
     if noise is None:
-        gdev = generator.device if generator is not None else x.device
-        noise = torch.randn(x.shape, generator=generator, device=gdev, dtype=torch.float32)
-    x = x + noise_aug_strength * noise.to(x.device)
+        gdev = generator.device if generator is not None else img.device
+        noise = torch.randn(img.shape, generator=generator, device=gdev, dtype=torch.float32)
+    x = noise.to(img.device, torch.float32).clone().contiguous()
+    ops.axpby_f32_(img, x, a=2.0, b=float(noise_aug_strength))         # x = 2*image + strength*noise
+    ops.axpby_f32_(torch.ones_like(img), x, a=-1.0, b=1.0)             #     - 1
     lat = vae.encode(x).latent_dist.mode()
     return torch.cat([torch.zeros_like(lat), lat]) if do_classifier_free_guidance else lat

@@ -132,7 +132,12 @@ def resize_bicubic_ac(x, Ho, Wo):
                          align_corners=True).reshape(*shape[:-2], Ho, Wo)
 
 
-NAMES = ["igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
+def axpby_f32_(x, y, a=1.0, b=1.0):
+    y.copy_(a * x + b * y)
+    return y
+
+
+NAMES = ["axpby_f32_", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
          "tokens_to_nchw", "patchify", "filter1d_reflect", "resize_bicubic_ac"]
 
 
