@@ -41,6 +41,16 @@ struct RowGeo {   // two registers per DMA row group (the 192x128 tile keeps six
 
 __device__ __attribute__((aligned(128))) f16 g_zero_page[128];  // source of out-of-image taps / rows beyond M
 
+// experiment switches of tools/igemm_trace.hip (the shipped library is built with the defaults):
+//   IGEMM_SPREAD  MFMA groups (of 4 per K step) over which the next stage's DMA instructions are issued
+//   IGEMM_EXP     1: no refill DMA in the K loop, 2: no MFMA (fragment reads kept) -- timing diagnostics, wrong results
+#ifndef IGEMM_SPREAD
+#define IGEMM_SPREAD 4
+#endif
+#ifndef IGEMM_EXP
+#define IGEMM_EXP 0
+#endif
+
 #ifdef MOFA_IGEMM_TRACE   // tools/igemm_trace.hip: per-workgroup tick sums: [0] first-stage waits, [1] K loops, [2..6] epilogue parts, [3] tiles
 __device__ unsigned long long g_trace[8 * 1024];
 #define TRACE_DECL unsigned long long tr_t = __builtin_readcyclecounter(), tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -486,10 +496,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
             const char* sb = smem + cur * STB;
             char* nb = smem + nxt * STB;
             constexpr int OPS = XI + WI, NG = BKS / 16;      // DMA instructions per stage, MFMA groups per stage
+            constexpr int SPREAD = IGEMM_SPREAD;             // the refill is issued over the first SPREAD MFMA groups
 #pragma unroll
             for (int kk = 0; kk < NG; ++kk) {
+#if IGEMM_EXP != 1
 #pragma unroll
-                for (int o = kk * OPS / NG; o < (kk + 1) * OPS / NG; ++o) {
+                for (int o = (kk * OPS / SPREAD < OPS ? kk * OPS / SPREAD : OPS);
+                     o < ((kk + 1) * OPS / SPREAD < OPS ? (kk + 1) * OPS / SPREAD : OPS); ++o) {
                     if (o < XI) {
                         const f16* sp = xs[o] ? xs[o] + ikc * BKS + xoff[o] : (const f16*)g_zero_page;
                         glds16(sp, nb + (wave * XI + o) * 1024);
@@ -497,17 +510,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
                         glds16(wsrc[o - XI] + (size_t)ksw * BKS, nb + SXB + (wave * WI + (o - XI)) * 1024);
                     }
                 }
+#endif
                 const int slot = ((kk * 2 + lh) ^ fsw) * 16;
                 f16x8 xf[MI], wf[NJ];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8*)(sb + xrow + i * 32 * RB + slot);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) wf[j] = *(const f16x8*)(sb + wrow + j * 32 * RB + slot);
+#if IGEMM_EXP == 2
+#pragma unroll
+                for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(xf[i]));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(wf[j]));
+#else
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+#endif
             }
             ++ksw;
             if (++ikc == kpt) { ikc = 0; ++itap; }
