@@ -195,3 +195,59 @@ def test_pipeline_conditioning_from_image():
     pil = Image.fromarray((img[0].permute(1, 2, 0).numpy() * 255).round().astype(np.uint8))
     emb2, il2 = pipe._conditioning(pil, None, None, H, W, 0.02, torch.Generator().manual_seed(13))
     assert rel_l2(emb2, want_emb) < 2e-2 and rel_l2(il2, want_il) < 2e-2        # 8-bit quantised copy of the same image
+
+
+def test_pipeline_from_image_end_to_end():
+    """The reference call with nothing precomputed: image in, latents / frames out (pipeline.py:293-527), seeded
+    generator: the noise-augmentation draw comes first, then the initial latents (pipeline.py:340, :379).  Oracle chain:
+    encode_image -> encode_vae_image -> denoise -> decode on the same draws."""
+    from helpers import TINY, TINY_CN, TINY_VAE, oracle_models, synthetic_inputs
+    from mofa_video_amd.adapter import FlowControlNet
+    from mofa_video_amd.clip import CLIPVisionModelWithProjection
+    from mofa_video_amd.pipeline import FlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    from mofa_video_amd.unet import UNetSpatioTemporalConditionControlNetModel
+    from mofa_video_amd.vae import AutoencoderKLTemporalDecoder
+    from oracle.clip import CLIPVisionModelWithProjection as OracleClip
+    from oracle.frontend import encode_image, encode_vae_image
+    from oracle.pipeline import denoise
+    from oracle.scheduler import EulerDiscreteScheduler as OSch
+    from oracle.vae import AutoencoderKLTemporalDecoder as OracleVae, decode_latents as odecode
+    T, H, W, steps = 4, 256, 256, 2
+    ou, oc, _, sdu, sdc, sdv = oracle_models(TINY, seed=0, vae_cfg=TINY_VAE, cn_cfg=TINY_CN)
+    sdv = dict(sdv)
+    sdv.update(schema.synthetic_state_dict(schema.vae_encoder_schema(**TINY_VAE), seed=70))
+    ov = OracleVae(with_encoder=True, **TINY_VAE).eval()
+    ov.load_state_dict({k: v.float() for k, v in sdv.items()})
+    ccfg = dict(hidden_size=320, intermediate_size=640, num_hidden_layers=2, num_attention_heads=4,
+                projection_dim=TINY["cross_attention_dim"])
+    sdclip = schema.synthetic_state_dict(schema.clip_vision_schema(ccfg), seed=71)
+    oclip = OracleClip(ccfg).eval()
+    oclip.load_state_dict({k: v.float() for k, v in sdclip.items()})
+    inp = synthetic_inputs(T, H, W, cross_dim=TINY["cross_attention_dim"])
+    image01 = inp["cond"] * 0.5 + 0.5
+
+    g = torch.Generator().manual_seed(77)
+    noise = torch.randn(1, 3, H, W, generator=g)
+    lat0 = torch.randn(1, T, 4, H // 8, W // 8, generator=g)
+    with torch.no_grad():
+        emb = encode_image(oclip, image01)
+        il = encode_vae_image(ov, image01 * 2 - 1, noise, 0.02)
+        ref_lat = denoise(ou, oc, OSch(), lat0, il, emb, inp["cond"], inp["flow"], num_inference_steps=steps)
+        ref_frames = odecode(ov, ref_lat, T, decode_chunk_size=3)
+
+    pipe = FlowControlNetPipeline(vae=AutoencoderKLTemporalDecoder(sdv, TINY_VAE, DEV),
+                                  image_encoder=CLIPVisionModelWithProjection(sdclip, ccfg, DEV),
+                                  unet=UNetSpatioTemporalConditionControlNetModel(sdu, TINY, DEV),
+                                  controlnet=FlowControlNet(sdc, TINY_CN, DEV), scheduler=EulerDiscreteScheduler())
+    kw = dict(controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=H, width=W, num_frames=T,
+              num_inference_steps=steps, decode_chunk_size=3)
+    out = pipe(image01, generator=torch.Generator().manual_seed(77), output_type="latent", **kw).frames
+    e = rel_l2(out, ref_lat)
+    print(f"image -> latents ({steps} steps): rel-L2 {e:.3e}")
+    assert e < 2e-2, e
+    frames = pipe(image01, generator=torch.Generator().manual_seed(77), output_type="raw", **kw).frames
+    e2 = rel_l2(frames, ref_frames)
+    print(f"image -> frames: rel-L2 {e2:.3e}")
+    assert tuple(frames.shape) == tuple(ref_frames.shape) == (1, 3, T, H, W)
+    assert e2 < 3e-2, e2
