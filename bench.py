@@ -247,7 +247,10 @@ def main():
         ach = ig["flops"] / ig["seconds"] / 1e12
         at = summ.get("attn_spatial_kernel")
         traffic = None       # HBM bytes per launch from the committed PMC passes (not collectable live)
-        for tag in ("r01d", "r01c"):                                  # newest committed PMC summary (tools/profile_round.sh)
+        import glob
+        tags = sorted((os.path.basename(f).split("_")[0] for f in glob.glob(os.path.join(ROOT, "profiles", "r*_igemm_traffic.json"))),
+                      reverse=True)
+        for tag in tags:                                              # newest committed PMC summary (tools/profile_round.sh)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_igemm_traffic.json")))
                 traffic = dict(hbm_bytes_per_launch=round(tj["hbm_bytes_per_launch"]),

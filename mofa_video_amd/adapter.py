@@ -14,7 +14,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .blocks import BIG, Conv3x3, Ctx, DownBlock, Linear, MidBlock, Sub, TimeEmbedding
+from .blocks import BIG, Conv3x3, Ctx, DownBlock, Linear, MidBlock, Sub, TembBatch, TimeEmbedding
 from .unet import DEFAULT_CONFIG, _Config
 
 
@@ -62,11 +62,12 @@ class FlowControlNet:
         self.conv_in = Conv3x3(s.sub("conv_in"))
         self.in_ld = self.conv_in.w.shape[1] // 9
         self.time = TimeEmbedding(s, boc[0], cfg["addition_time_embed_dim"])
-        self.down_blocks = []
-        for i, t in enumerate(cfg["down_block_types"]):
-            self.down_blocks.append(DownBlock(s.sub(f"down_blocks.{i}"), lpb, heads[i], cross=t.startswith("CrossAttn"),
-                                              downsample=(i != n - 1)))
-        self.mid_block = MidBlock(s.sub("mid_block"), heads[-1])
+        with TembBatch() as self.temb_batch:          # every time_emb_proj of the trunk -> one GEMM per step
+            self.down_blocks = []
+            for i, t in enumerate(cfg["down_block_types"]):
+                self.down_blocks.append(DownBlock(s.sub(f"down_blocks.{i}"), lpb, heads[i], cross=t.startswith("CrossAttn"),
+                                                  downsample=(i != n - 1)))
+            self.mid_block = MidBlock(s.sub("mid_block"), heads[-1])
         nz = 0
         while s.has(f"controlnet_down_blocks.{nz}.weight"):
             nz += 1
@@ -132,6 +133,7 @@ class FlowControlNet:
         if half is not None:
             ids = ids[half:half + B]
         c.temb_act = self.time(ts, ids.contiguous())
+        c.temb_all = self.temb_batch.run(c.temb_act)
         if c.ctx16 is None:
             e = encoder_hidden_states.to(self.device, torch.float32)
             e = e.reshape(e.shape[0], -1).contiguous()

@@ -51,6 +51,7 @@ class Ctx:
         self.B, self.T = B, T
         self.N = B * T
         self.temb_act = None      # fp16 [B, temb_dim] = silu(emb); None for the VAE
+        self.temb_all = None      # fp32 [B, total]: every time_emb_proj of the network in one GEMM (TembBatch)
         self.ctx16 = None         # fp16 [B, cross_dim] image embedding (first frame's == every frame's)
         self.cache = {}           # timestep-invariant per-layer vectors (cross-attention, frame-position emb)
         self.time_context_hw_major = True
@@ -136,6 +137,48 @@ def _sigmoid(v):
 
 
 # ---------------------------------------------------------------------------------------------------------
+class TembBatch:
+    """All ``time_emb_proj`` layers of one network (44 in the SVD UNet, 20 in the ControlNet trunk; each a
+    [Cout, 1280] x [B, 1280] product) as ONE implicit-GEMM launch + one cast per denoise step instead of two launches
+    per layer.  Blocks built inside ``with TembBatch() as tb:`` register their projection and remember the column
+    offset; the row width is padded to a common multiple of every Cout so that a layer's [B, Cout] slice of the
+    [B, total] result is addressable as the igemm row vector with ``rv_mul = total / Cout`` (include/mofa_hip.h)."""
+    _active = None
+
+    def __init__(self):
+        self.items, self.total, self.w, self.b = [], 0, None, None
+
+    def __enter__(self):
+        self._prev, TembBatch._active = TembBatch._active, self
+        return self
+
+    def __exit__(self, *exc):
+        TembBatch._active = self._prev
+        if exc[0] is None and self.items:
+            mult = 1
+            for lin in self.items:
+                mult = mult * lin.n_real // math.gcd(mult, lin.n_real)
+            pad = (-self.total) % mult
+            ws, bs = [lin.w for lin in self.items], [lin.b for lin in self.items]
+            if pad:
+                ws.append(ws[0].new_zeros((pad, ws[0].shape[1])))
+                bs.append(bs[0].new_zeros((pad,)))
+            self.w, self.b = torch.cat(ws, 0).contiguous(), torch.cat(bs, 0).contiguous()
+            for lin in self.items:                      # the per-layer copies are no longer needed
+                lin.w = lin.b = None
+        return False
+
+    def add(self, lin):
+        assert lin.w.shape[0] == lin.n_real and lin.n_real % 64 == 0 and lin.b is not None
+        off = self.total
+        self.items.append(lin)
+        self.total += lin.n_real
+        return off
+
+    def run(self, temb_act):
+        return ops.cast_f16_to_f32(ops.igemm(temb_act, self.w, self.b)) if self.w is not None else None
+
+
 class SpatioTemporalResBlock:
     """diffusers SpatioTemporalResBlock = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender."""
 
@@ -144,21 +187,28 @@ class SpatioTemporalResBlock:
         self.norm1, self.norm2 = GroupNorm(sp.sub("norm1"), eps), GroupNorm(sp.sub("norm2"), eps)
         self.conv1, self.conv2 = Conv3x3(sp.sub("conv1")), Conv3x3(sp.sub("conv2"))
         self.temb = Linear(sp.sub("time_emb_proj")) if sp.has("time_emb_proj.weight") else None
+        tb = TembBatch._active
+        self.temb_off = tb.add(self.temb) if (tb is not None and self.temb is not None) else None
         self.shortcut = Linear(sp.sub("conv_shortcut")) if sp.has("conv_shortcut.weight") else None
         te = temporal_eps if temporal_eps is not None else eps
         self.tnorm1, self.tnorm2 = GroupNorm(tp.sub("norm1"), te), GroupNorm(tp.sub("norm2"), te)
         self.tconv1, self.tconv2 = ConvT3(tp.sub("conv1")), ConvT3(tp.sub("conv2"))
         self.ttemb = Linear(tp.sub("time_emb_proj")) if tp.has("time_emb_proj.weight") else None
+        self.ttemb_off = tb.add(self.ttemb) if (tb is not None and self.ttemb is not None) else None
         alpha = _sigmoid(s.get("time_mixer.mix_factor").reshape(-1)[0])
         self.alpha = (1.0 - alpha) if switch else alpha   # weight of x_spatial
 
     def __call__(self, x, c, H, W):
         HW, N, T = H * W, c.N, c.T
-        rv = dict(rv=(T * HW, 1, 1, BIG))
+
+        def tvec(lin, off):
+            """fp32 [B, Cout] time-embedding vector of this layer + the row-vector index mapping that reads it"""
+            if off is not None and c.temb_all is not None:
+                return dict(rowvec=c.temb_all[:, off:off + lin.n_real], rv=(T * HW, c.temb_all.shape[1] // lin.n_real, 1, BIG))
+            return dict(rowvec=ops.cast_f16_to_f32(lin(c.temb_act)), rv=(T * HW, 1, 1, BIG))
         h = self.norm1(x, N, HW, silu=True)
         if self.temb is not None:
-            tv = ops.cast_f16_to_f32(self.temb(c.temb_act))
-            h = self.conv1(h, H, W, rowvec=tv, **rv)
+            h = self.conv1(h, H, W, **tvec(self.temb, self.temb_off))
         else:
             h = self.conv1(h, H, W)
         h = self.norm2(h, N, HW, silu=True)
@@ -168,8 +218,7 @@ class SpatioTemporalResBlock:
         if par is None:
             g = self.tnorm1(xs, N, HW, frames_per_stat=T, silu=True)
             if self.ttemb is not None:
-                tv = ops.cast_f16_to_f32(self.ttemb(c.temb_act))
-                g = self.tconv1(g, T, HW, rowvec=tv, **rv)
+                g = self.tconv1(g, T, HW, **tvec(self.ttemb, self.ttemb_off))
             else:
                 g = self.tconv1(g, T, HW)
             g = self.tnorm2(g, N, HW, frames_per_stat=T, silu=True)
@@ -184,8 +233,7 @@ class SpatioTemporalResBlock:
         ext = par.halo(g, HW)
         kw = dict(geom=ops.convt3_geom(0, HW), M=M)
         if self.ttemb is not None:
-            tv = ops.cast_f16_to_f32(self.ttemb(c.temb_act))
-            g = ops.igemm(ext[HW:], self.tconv1.w, self.tconv1.b, rowvec=tv, **rv, **kw)
+            g = ops.igemm(ext[HW:], self.tconv1.w, self.tconv1.b, **tvec(self.ttemb, self.ttemb_off), **kw)
         else:
             g = ops.igemm(ext[HW:], self.tconv1.w, self.tconv1.b, **kw)
         g = ops.group_norm(g, self.tnorm2.g, self.tnorm2.b, N, HW, self.tnorm2.eps, **gn)

@@ -134,7 +134,10 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     if bias is not None:
         _chk(bias, F32); assert bias.numel() == N
     if rowvec is not None:
-        _chk(rowvec, F32); assert rowvec.dim() == 2 and rowvec.shape[1] == N and rowvec.is_contiguous()
+        # rows of a wider fp32 matrix are allowed: the kernel addresses row idx at idx*N, so the caller's rv_mul must
+        # carry the row stride (TembBatch: stride = total, rv_mul = total / N)
+        _chk(rowvec, F32); assert rowvec.dim() == 2 and rowvec.shape[1] == N and rowvec.stride(1) == 1
+        assert rowvec.is_contiguous() or (rowvec.stride(0) % N == 0 and rv[1] == rowvec.stride(0) // N), (rowvec.stride(), N, rv)
     a.M, a.N, a.Cin = M, N, Cin
     a.ldx, a.ldo = _ld(x), _ld(out)
     a.ldr1 = _ld(r1) if r1 is not None else 0

@@ -8,7 +8,7 @@ entry the pipeline uses (token-major fp16 in/out).
 import torch
 
 from . import ops
-from .blocks import BIG, Conv3x3, Ctx, DownBlock, GroupNorm, MidBlock, Sub, TimeEmbedding, UpBlock
+from .blocks import BIG, Conv3x3, Ctx, DownBlock, GroupNorm, MidBlock, Sub, TembBatch, TimeEmbedding, UpBlock
 
 SVD_XT_HEADS = (5, 10, 20, 20)
 DEFAULT_CONFIG = dict(in_channels=8, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
@@ -46,16 +46,17 @@ class UNetSpatioTemporalConditionControlNetModel:
         lpb = cfg["layers_per_block"]
         self.conv_in = Conv3x3(s.sub("conv_in"))
         self.time = TimeEmbedding(s, boc[0], cfg["addition_time_embed_dim"])
-        self.down_blocks = []
-        for i, t in enumerate(cfg["down_block_types"]):
-            self.down_blocks.append(DownBlock(s.sub(f"down_blocks.{i}"), lpb, heads[i], cross=t.startswith("CrossAttn"),
-                                              downsample=(i != n - 1)))
-        self.mid_block = MidBlock(s.sub("mid_block"), heads[-1])
-        rh = list(reversed(heads))
-        self.up_blocks = []
-        for i, t in enumerate(cfg["up_block_types"]):
-            self.up_blocks.append(UpBlock(s.sub(f"up_blocks.{i}"), lpb + 1, rh[i], cross=t.startswith("CrossAttn"),
-                                          upsample=(i != n - 1)))
+        with TembBatch() as self.temb_batch:          # every time_emb_proj of the network -> one GEMM per step
+            self.down_blocks = []
+            for i, t in enumerate(cfg["down_block_types"]):
+                self.down_blocks.append(DownBlock(s.sub(f"down_blocks.{i}"), lpb, heads[i], cross=t.startswith("CrossAttn"),
+                                                  downsample=(i != n - 1)))
+            self.mid_block = MidBlock(s.sub("mid_block"), heads[-1])
+            rh = list(reversed(heads))
+            self.up_blocks = []
+            for i, t in enumerate(cfg["up_block_types"]):
+                self.up_blocks.append(UpBlock(s.sub(f"up_blocks.{i}"), lpb + 1, rh[i], cross=t.startswith("CrossAttn"),
+                                              upsample=(i != n - 1)))
         self.conv_norm_out = GroupNorm(s.sub("conv_norm_out"), 1e-5)
         self.conv_out = Conv3x3(s.sub("conv_out"))
         self.in_ld = self.conv_in.w.shape[1] // 9      # channel-padded input width (64)
@@ -76,6 +77,7 @@ class UNetSpatioTemporalConditionControlNetModel:
         if half is not None:
             ids = ids[half:half + B]
         c.temb_act = self.time(ts, ids.contiguous())
+        c.temb_all = self.temb_batch.run(c.temb_act)
         if c.ctx16 is None:
             e = encoder_hidden_states.to(self.device, torch.float32)
             e = e.reshape(e.shape[0], -1).contiguous()

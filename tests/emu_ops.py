@@ -42,7 +42,9 @@ def igemm(x, w, bias=None, geom=None, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30)
     if rowvec is not None:
         m = torch.arange(M)
         idx = ((m // rv[0]) * rv[1] + (m % rv[2])) % rv[3]
-        y = y + rowvec.float()[idx]
+        # the kernel addresses row idx at base + idx*N whatever the view's own row stride is
+        rows = torch.as_strided(rowvec, (int(idx.max()) + 1, N), (N, 1))
+        y = y + rows.float()[idx]
     y = y * s_acc
     if r1 is not None:
         y = y + s1 * r1[:, :N].float()
@@ -137,7 +139,15 @@ def axpby_f32_(x, y, a=1.0, b=1.0):
     return y
 
 
-NAMES = ["axpby_f32_", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
+def cast_f16_to_f32(x):
+    return x.float()
+
+
+def cast_f32_to_f16(x):
+    return x.half()
+
+
+NAMES = ["axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
          "tokens_to_nchw", "patchify", "filter1d_reflect", "resize_bicubic_ac"]
 
 

@@ -110,3 +110,32 @@ def test_pipeline_conditioning_rng_order_and_pil(emu):
         pipe._conditioning(None, None, None, H, W, 0.02, None)
     with pytest.raises(ValueError):
         pipe._conditioning(torch.rand(1, 3, H + 8, W), None, None, H, W, 0.02, None)
+
+
+def test_temb_batch_row_vector_addressing(emu):
+    """TembBatch: all time_emb_proj layers in one GEMM; a layer's [B, Cout] slice of the [B, total] result is read as the
+    igemm row vector through rv_mul = total / Cout (blocks.py).  Same numbers as one GEMM per layer."""
+    from mofa_video_amd import ops
+    from mofa_video_amd.blocks import BIG, Linear, Sub, TembBatch
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    couts = [64, 128, 64, 320, 128]
+    for i, n in enumerate(couts):
+        sd[f"l{i}.weight"] = torch.randn(n, 256, generator=g) / 16
+        sd[f"l{i}.bias"] = torch.randn(n, generator=g)
+    ref = [Linear(Sub(sd, f"l{i}.", "cpu")) for i in range(len(couts))]
+    with TembBatch() as tb:
+        lins = [Linear(Sub(sd, f"l{i}.", "cpu")) for i in range(len(couts))]
+        offs = [tb.add(l) for l in lins]
+    assert offs == [0, 64, 192, 256, 576] and tb.w.shape[0] % 640 == 0 and tb.w.shape[0] >= sum(couts)   # lcm(64,128,320)
+    assert all(l.w is None for l in lins)
+    B, T, HW = 2, 3, 8
+    temb = torch.randn(B, 256, generator=g).half()
+    allv = tb.run(temb)
+    assert allv.dtype == torch.float32 and tuple(allv.shape) == (B, tb.w.shape[0])
+    x = torch.randn(B * T * HW, 64, generator=g).half()
+    for lin, n, off in zip(ref, couts, offs):
+        w = (torch.randn(n, 64, generator=g) / 8).half()
+        want = ops.igemm(x, w, rowvec=ops.cast_f16_to_f32(lin(temb)), rv=(T * HW, 1, 1, BIG))
+        got = ops.igemm(x, w, rowvec=allv[:, off:off + n], rv=(T * HW, allv.shape[1] // n, 1, BIG))
+        assert torch.equal(want, got), n
