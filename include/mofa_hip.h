@@ -84,8 +84,9 @@ int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Attention.  q/k/v are column blocks of token-major matrices: element (token, head, d) at
- * base[token*ld + head*64 + d].  Replaces diffusers AttnProcessor2_0 / F.scaled_dot_product_attention
- * inside BasicTransformerBlock.attn1 (spatial) and TemporalBasicTransformerBlock.attn1 (temporal).
+ * base[token*ld + head*head_dim + d].  Replaces diffusers AttnProcessor2_0 / F.scaled_dot_product_attention
+ * inside BasicTransformerBlock.attn1 (spatial) and TemporalBasicTransformerBlock.attn1 (temporal), and the
+ * softmax(QK^T)V of transformers CLIPAttention (head dim 80 in 128-column slots, mofa_video_amd/clip.py).
  * ---------------------------------------------------------------------------------------- */
 /* spatial self-attention, head_dim 64 or 128: batch = nframes, sequence = S tokens per frame.
  * (The MOFA ControlNet trunk is built with heads (5,10,10,20) -- FlowControlNet calls super().__init__()
