@@ -594,6 +594,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
     TRACE_FLUSH();
 }
 
+#ifdef MOFA_IGEMM_RING3   // experimental 3-stage 256x128 variant: tools only, see the header of the included file
+#include "igemm_ring3.inc"
+static int s_ring3_on = -1;      // -1: read MOFA_IGEMM_CFG (5 = on); tools/igemm_ring3_check.hip flips it between launches
+static bool s_ring3_attr = false;
+#endif
+
 extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (!a || !a->x || !a->w || !a->out) return MOFA_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->Cin <= 0) return MOFA_EINVAL;
@@ -667,7 +673,27 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
             if (k == 0 || cost < best) { best = cost; ci = k; }
         }
     }
+#ifdef MOFA_IGEMM_RING3
+    // MOFA_IGEMM_CFG=5: the experimental 3-stage 256x128 kernel (needs >= 4 K steps), otherwise the normal choice
+    static const Cfg ring3 = {{igemm3_f16_kernel<4, 2, 2, 0>, igemm3_f16_kernel<4, 2, 2, 1>, igemm3_f16_kernel<4, 2, 2, 2>,
+                               igemm3_f16_kernel<4, 2, 2, 3>, igemm3_f16_kernel<4, 2, 2, 4>, igemm3_f16_kernel<4, 2, 2, 5>,
+                               igemm3_f16_kernel<4, 2, 2, 6>, igemm3_f16_kernel<4, 2, 2, 7>, igemm3_f16_kernel<4, 2, 2, 8>},
+                              256, 128, 512, 3 * 384 * 128 + 2 * EPI_SLAB_BYTES, 1};
+    if (s_ring3_on < 0) {
+        const char* e5 = getenv("MOFA_IGEMM_CFG");
+        s_ring3_on = (e5 && atoi(e5) == 5) ? 1 : 0;
+    }
+    if (s_ring3_on == 1 && !s_ring3_attr) {
+        for (kern_t k : ring3.k)
+            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, ring3.lds) != hipSuccess)
+                return MOFA_ELAUNCH;
+        s_ring3_attr = true;
+    }
+    const bool use_ring3 = s_ring3_on == 1 && Ktot / 64 >= 4;
+    const Cfg& c = use_ring3 ? ring3 : cfgs[ci];
+#else
     const Cfg& c = cfgs[ci];
+#endif
     const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
     const long long nt = (long long)tilesM * tilesN;
     if (nt > 0x7fffffffLL) return MOFA_EINVAL;
