@@ -13,9 +13,11 @@ entirely in libmofa_hip.so on token-major fp16 activations:
         mofa_cfg_euler_step         (CFG with per-frame guidance + v-prediction Euler step, fp32 latents)
     decode: temporal VAE decoder, chunks of ``decode_chunk_size`` frames.
 
-The CLIP image encoder and the VAE *encoder* run once per clip before the hot path and are not part of this
-package: pass ``image_embeddings`` ([1,1,1024] or [2,1,1024]) and ``image_latents``
-([1,4,h,w] or [2,4,h,w]) directly, or supply ``image_encoder`` / a ``vae`` with ``encode`` yourself.
+Image conditioning (once per clip before the loop, pipeline.py:330-352) also runs on the library when the
+pipeline holds an ``image_encoder`` (mofa_video_amd.clip) and a VAE with encoder weights: ``image`` is then the PIL image /
+[1,3,H,W] tensor in [0, 1] of the reference call (mofa_video_amd/frontend.py).  Precomputed conditioning can be passed
+instead through the keyword-only extensions ``image_embeddings`` ([1,1,1024] or [2,1,1024]) and ``image_latents``
+([1,4,h,w] or [2,4,h,w]).
 Reference quirks kept: ``added_time_ids`` is always [6, 128, 0.02] (pipeline.py:430-440); CFG is always on
 (max_guidance_scale > 1); the scheduler's unused per-step randn draw is not reproduced (no effect on results).
 """
@@ -38,11 +40,11 @@ class FlowControlNetPipelineOutput:
 
 
 def _to_tensor_image(image, height, width, device):
-    """VaeImageProcessor.preprocess for tensors in [0,1] / [-1,1] is a resize + (2x-1); here only tensors that
-    are already H x W are accepted (resizing belongs to the once-per-clip front end)."""
+    """controlnet_condition: VaeImageProcessor.preprocess for tensors is a resize + (2x-1); here only tensors in [-1,1]
+    that are already H x W are accepted (the conditioning *image* goes through frontend.image_to_01 instead)."""
     if not torch.is_tensor(image):
         raise ValueError("mofa_video_amd pipeline expects a torch tensor [1,3,H,W] in [-1,1] for image / "
-                         f"controlnet_condition (PIL preprocessing is outside the hot path), got {type(image)}")
+                         f"controlnet_condition, got {type(image)}")
     if image.dim() == 3:
         image = image.unsqueeze(0)
     if tuple(image.shape[-2:]) != (height, width):
