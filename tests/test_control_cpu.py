@@ -56,3 +56,28 @@ def test_drags_and_merge():
     m = control.merge_inmask_outmask(fin, fout)
     assert m[0, 0, :, 0, 0].tolist() == [1.0, 2.0] and m[0, 0, :, 0, 1].tolist() == [7.0, 7.0] and (m[0, 1] == 7).all()
     del a
+
+
+def test_edge_cases_of_the_rasterisers():
+    """ragged / degenerate inputs the reference functions accept (Traj/run_gradio.py:41-86, :162-177): two tracks that
+    start on the same pixel accumulate, an empty brush group stays an empty array, a two-point track is a straight line,
+    the backward flag only flips the sign."""
+    import numpy as np
+    from mofa_video_amd import control
+    line = control.interpolate_trajectory([(10, 20), (30, 60)], 5)
+    assert np.allclose(np.array(line), np.stack([np.linspace(10, 30, 5), np.linspace(20, 60, 5)], 1))
+    a = np.array(control.interpolate_trajectory([(5, 5), (9, 7), (20, 8)], 4))
+    b = np.array(control.interpolate_trajectory([(5, 5), (6, 11), (7, 30)], 4))
+    pts = np.stack([a, b])                                            # both start at pixel (5, 5)
+    flow, mask = control.get_sparseflow_and_mask_forward(pts, 3, 32, 32)
+    assert mask.sum() == 2 * 3 and (mask[:, 5, 5] == 2).all()
+    want = np.int64(a[1:] - a[0]) + np.int64(b[1:] - b[0])
+    assert np.array_equal(flow[:, 5, 5], want) and np.count_nonzero(flow) == np.count_nonzero(want)
+    back, _ = control.get_sparseflow_and_mask_forward(pts, 3, 32, 32, is_backward_flow=True)
+    assert np.array_equal(back, -flow)
+    brush = np.zeros((32, 32), dtype=np.uint8)                       # nothing brushed: every track is "outside"
+    inm, outm = control.divide_points_afterinterpolate(pts, brush)
+    assert inm.size == 0 and outm.shape == pts.shape
+    brush[:] = 255
+    inm, outm = control.divide_points_afterinterpolate(pts, brush)
+    assert outm.size == 0 and inm.shape == pts.shape
