@@ -20,6 +20,7 @@ int main(int argc, char** argv) {
     mofa_igemm_args a = {};
     a.x = x; a.w = w; a.out = o; a.M = M; a.N = N; a.Cin = K; a.ldx = K; a.ldo = nout; a.mode = 0; a.act = act;
     a.s_acc = 1.0f; a.rv_div = a.rv_mul = a.rv_mod_in = a.rv_mod_out = 1;
+    if (argc > 5) a.ldx = atoi(argv[5]);   // timing diagnostic: ldx = 0 makes every activation row alias row 0 (all refill reads hit L1 / L2)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) if (mofa_igemm_f16(&a, nullptr)) { printf("launch failed\n"); return 1; }
     hipDeviceSynchronize();
