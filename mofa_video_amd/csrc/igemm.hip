@@ -43,7 +43,8 @@ __device__ __attribute__((aligned(128))) f16 g_zero_page[128];  // source of out
 
 // experiment switches of tools/igemm_trace.hip (the shipped library is built with the defaults):
 //   IGEMM_SPREAD  MFMA groups (of 4 per K step) over which the next stage's DMA instructions are issued
-//   IGEMM_EXP     1: no refill DMA in the K loop, 2: no MFMA (fragment reads kept) -- timing diagnostics, wrong results
+//   IGEMM_EXP     1: no refill DMA in the K loop, 2: no MFMA (fragment reads kept), 3: refill + barriers only (no fragment
+//                 reads, no MFMA) -- timing diagnostics, wrong results
 #ifndef IGEMM_SPREAD
 #define IGEMM_SPREAD 4
 #endif
@@ -510,6 +511,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
                         glds16(wsrc[o - XI] + (size_t)ksw * BKS, nb + SXB + (wave * WI + (o - XI)) * 1024);
                     }
                 }
+#endif
+#if IGEMM_EXP == 3
+                (void)sb;
+                continue;                                     // refill + barriers only: no fragment reads, no MFMA
 #endif
                 const int slot = ((kk * 2 + lh) ^ fsw) * 16;
                 f16x8 xf[MI], wf[NJ];
