@@ -605,6 +605,15 @@ static int s_ring3_on = -1;      // -1: read MOFA_IGEMM_CFG (5 = on); tools/igem
 static bool s_ring3_attr = false;
 #endif
 
+#ifdef MOFA_IGEMM_PC      // experimental producer / consumer 128x128 variant: tools only, see the header of the included file
+#ifndef IGEMM_PC_PROD
+#define IGEMM_PC_PROD 2
+#endif
+#include "igemm_pc.inc"
+static int s_pc_on = -1;         // -1: read MOFA_IGEMM_CFG (6 = on); tools/igemm_pc_check.hip flips it between launches
+static bool s_pc_attr = false;
+#endif
+
 extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (!a || !a->x || !a->w || !a->out) return MOFA_EINVAL;
     if (a->M <= 0 || a->N <= 0 || a->Cin <= 0) return MOFA_EINVAL;
@@ -678,6 +687,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
             if (k == 0 || cost < best) { best = cost; ci = k; }
         }
     }
+    const Cfg* sel = &cfgs[ci];
 #ifdef MOFA_IGEMM_RING3
     // MOFA_IGEMM_CFG=5: the experimental 3-stage 256x128 kernel (needs >= 4 K steps), otherwise the normal choice
     static const Cfg ring3 = {{igemm3_f16_kernel<4, 2, 2, 0>, igemm3_f16_kernel<4, 2, 2, 1>, igemm3_f16_kernel<4, 2, 2, 2>,
@@ -694,11 +704,26 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
                 return MOFA_ELAUNCH;
         s_ring3_attr = true;
     }
-    const bool use_ring3 = s_ring3_on == 1 && Ktot / 64 >= 4;
-    const Cfg& c = use_ring3 ? ring3 : cfgs[ci];
-#else
-    const Cfg& c = cfgs[ci];
+    if (s_ring3_on == 1 && Ktot / 64 >= 4) sel = &ring3;
 #endif
+#ifdef MOFA_IGEMM_PC
+    // MOFA_IGEMM_CFG=6: the experimental producer / consumer kernel for the plain, r1 and GEGLU epilogue kinds
+    static const Cfg pc = {{igemm_pc_f16_kernel<0, IGEMM_PC_PROD>, igemm_pc_f16_kernel<1, IGEMM_PC_PROD>, nullptr, nullptr, nullptr,
+                            nullptr, nullptr, nullptr, igemm_pc_f16_kernel<8, IGEMM_PC_PROD>},
+                           128, 128, 64 * (4 + IGEMM_PC_PROD), 2 * 256 * 128, 2};
+    if (s_pc_on < 0) {
+        const char* e6 = getenv("MOFA_IGEMM_CFG");
+        s_pc_on = (e6 && atoi(e6) == 6) ? 1 : 0;
+    }
+    if (s_pc_on == 1 && !s_pc_attr) {
+        for (kern_t k : pc.k)
+            if (k && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, pc.lds) != hipSuccess)
+                return MOFA_ELAUNCH;
+        s_pc_attr = true;
+    }
+    if (s_pc_on == 1 && pc.k[kind]) sel = &pc;
+#endif
+    const Cfg& c = *sel;
     const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
     const long long nt = (long long)tilesM * tilesN;
     if (nt > 0x7fffffffLL) return MOFA_EINVAL;
