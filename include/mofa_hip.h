@@ -76,9 +76,15 @@ typedef struct mofa_igemm_args {
                          * (Traj/models/cmp/models/backbone/resnet.py:118-129) */
     int32_t pad;        /* MOFA_MODE_CONV3X3: MOFA_PAD_SAME (0) = dil*(k/2) on every side; MOFA_PAD_TRAILING (1) = no
                          * leading padding, taps start at input pixel stride*o (diffusers Downsample2D(padding=0) of the
-                         * VAE encoder: F.pad(x, (0,1,0,1)) then a stride-2 conv).  sizeof(mofa_igemm_args) = 168     */
+                         * VAE encoder: F.pad(x, (0,1,0,1)) then a stride-2 conv)                                    */
+    int32_t tile;       /* MOFA_TILE_AUTO (0): the launcher's cost model picks the output tile; any other MOFA_TILE_*
+                         * forces it (parity tests run every shape through every tile).  sizeof(mofa_igemm_args) = 168 */
 } mofa_igemm_args;
 enum { MOFA_PAD_SAME = 0, MOFA_PAD_TRAILING = 1 };
+/* output tiles of the implicit GEMM: 4 waves / 2 workgroups per CU (128x128, 192x128), 8 waves / 1 per CU with the
+ * 2-stage K loop (256x256), and the 8-wave phase-pipelined 256x256 tile the denoise loop mostly runs on (needs 16-byte
+ * aligned rows: MOFA_EINVAL if forced on an ineligible call) */
+enum { MOFA_TILE_AUTO = 0, MOFA_TILE_128X128 = 2, MOFA_TILE_256X256_2STAGE = 3, MOFA_TILE_192X128 = 4, MOFA_TILE_256X256 = 5 };
 
 int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
 

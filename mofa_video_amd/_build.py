@@ -5,7 +5,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmofa_hip.so")
-SOURCES = ["igemm.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip", "cmp_ops.hip",
+SOURCES = ["igemm.hip", "igemm8.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip", "cmp_ops.hip",
            "frontend.hip"]
 
 
@@ -14,6 +14,7 @@ def _stale():
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
+                                                      os.path.join(CSRC, "igemm_common.h"),
                                                       os.path.join(HERE, "..", "include", "mofa_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -26,120 +26,19 @@
 // row-vector loads are issued a group of passes at a time, on 128-row tiles one group ahead of the stores (vmcnt retires
 // in order on gfx9: a load issued before a store never waits for it).  The kernel is templated on the epilogue kind
 // (residuals / row vector / GEGLU) so the memory operations per pass are static.
-// Environment: MOFA_IGEMM_CFG=2|3|4 forces the 128x128 | 256x256 | 192x128 tile; MOFA_IGEMM_PERSIST=0 launches one
-// workgroup per tile (A/B of the persistent walk).
+// Tile choice: mofa_igemm_args.tile (MOFA_TILE_*; 0 = the launcher's cost model); the environment variable
+// MOFA_IGEMM_CFG=2|3|4|5 forces the 128x128 | 256x256 (this file's 2-stage loop) | 192x128 | 256x256 phase-pipelined
+// (igemm8.hip) tile for every launch that leaves `tile` at 0.
 // Earlier variants (register staging, 64-byte rows, deeper rings, 256x128 tiles) and their measurements:
 // profiles/r01_igemm_config_sweep.md.
 #include <stdlib.h>
 
-#include "common.h"
+#include "igemm_common.h"
 
-struct RowGeo {   // two registers per DMA row group (the 192x128 tile keeps six of these live through the K loop)
-    int a;        // plain / convT3: global output row m; conv: image index; -1 when the row is beyond M
-    int b;        // conv: (oy << 16) | ox of the output pixel; convT3: frame index within its clip
-};
-
-__device__ __attribute__((aligned(128))) f16 g_zero_page[128];  // source of out-of-image taps / rows beyond M
-
-// experiment switches of tools/igemm_trace.hip (the shipped library is built with the defaults):
-//   IGEMM_SPREAD  MFMA groups (of 4 per K step) over which the next stage's DMA instructions are issued
-//   IGEMM_EXP     1: no refill DMA in the K loop, 2: no MFMA (fragment reads kept), 3: refill + barriers only (no fragment
-//                 reads, no MFMA) -- timing diagnostics, wrong results
-#ifndef IGEMM_SPREAD
-#define IGEMM_SPREAD 4
-#endif
-#ifndef IGEMM_EXP
-#define IGEMM_EXP 0
+#ifndef IGEMM8_REL_COST
+#define IGEMM8_REL_COST 0.60   // relative cost per flop of the phase-pipelined 256x256 tile (see the cost model below)
 #endif
 
-#ifdef MOFA_IGEMM_TRACE   // tools/igemm_trace.hip: per-workgroup tick sums: [0] first-stage waits, [1] K loops, [2..6] epilogue parts, [3] tiles
-__device__ unsigned long long g_trace[8 * 1024];
-#define TRACE_DECL unsigned long long tr_t = __builtin_readcyclecounter(), tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define TRACE_ADD(slot) do { const unsigned long long t__ = __builtin_readcyclecounter(); tr_acc[slot] += t__ - tr_t; tr_t = t__; } while (0)
-#define TRACE_FLUSH() do { if (threadIdx.x == 0 && blockIdx.x < 1024) for (int i__ = 0; i__ < 8; ++i__) g_trace[blockIdx.x * 8 + i__] = tr_acc[i__]; } while (0)
-#else
-#define TRACE_DECL do { } while (0)
-#define TRACE_ADD(slot) do { } while (0)
-#define TRACE_FLUSH() do { } while (0)
-#endif
-
-__device__ __forceinline__ RowGeo make_geo(const mofa_igemm_args& a, int m) {
-    RowGeo g;
-    g.a = (m < a.M) ? m : -1;
-    g.b = 0;
-    if (a.mode == MOFA_MODE_CONV3X3) {
-        const int hw = a.Hout * a.Wout;
-        const int img = m / hw, rem = m - img * hw;
-        const int oy = rem / a.Wout;
-        g.a = (m < a.M) ? img : -1;
-        g.b = (oy << 16) | (rem - oy * a.Wout);
-    } else if (a.mode == MOFA_MODE_CONVT3) {
-        g.b = a.T > 0 ? (m / a.HW) % a.T : 0;
-    }
-    return g;
-}
-
-__device__ __forceinline__ const f16* x_src(const mofa_igemm_args& a, const RowGeo& g, int tap) {
-    if (g.a < 0) return nullptr;
-    const f16* x = (const f16*)a.x;
-    if (a.mode == MOFA_MODE_PLAIN) {
-        return x + (size_t)g.a * a.ldx;
-    } else if (a.mode == MOFA_MODE_CONV3X3) {
-        const int ks = a.ksize > 0 ? a.ksize : 3;
-        const int dil = a.dil > 0 ? a.dil : 1;
-        const int ky = tap / ks, kx = tap - ky * ks;
-        const int org = a.pad == MOFA_PAD_TRAILING ? 0 : (ks >> 1);
-        const int vy = (g.b >> 16) * a.stride + (ky - org) * dil;
-        const int vx = (g.b & 0xffff) * a.stride + (kx - org) * dil;
-        if (vy < 0 || vx < 0 || vy >= a.Hin * a.up || vx >= a.Win * a.up) return nullptr;
-        const int iy = (a.up == 2) ? (vy >> 1) : vy;
-        const int ix = (a.up == 2) ? (vx >> 1) : vx;
-        return x + ((size_t)(g.a * a.Hin + iy) * a.Win + ix) * a.ldx;
-    } else {  // MOFA_MODE_CONVT3
-        const int tt = g.b + tap - 1;
-        if (a.T > 0 && (tt < 0 || tt >= a.T)) return nullptr;   // T == 0: unclipped, caller supplies halo frames
-        return x + ((size_t)g.a + (size_t)(tap - 1) * a.HW) * a.ldx;
-    }
-}
-
-// XCD-aware persistent tile walk: the hardware deals workgroup ids round-robin over the 8 XCDs, so workgroup b lives on
-// XCD b & 7.  Each XCD gets a CONTIGUOUS range of tile ids (bijective split of ntiles into 8 ranges) and its resident
-// workgroups walk that range with stride (workgroups per XCD): at any time one XCD works on neighbouring tiles (same
-// activation row block, successive weight column blocks) and the activation tile is served from that XCD's L2.
-struct TileWalk {
-    int start, count, local, stride;
-    __device__ __forceinline__ void init(int ntiles) {
-        const int xcd = blockIdx.x & 7, q = ntiles >> 3, r = ntiles & 7;
-        start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        count = q + (xcd < r ? 1 : 0);
-        local = blockIdx.x >> 3;
-        stride = gridDim.x >> 3;
-    }
-};
-
-#ifndef IGEMM_INTERLEAVE
-#define IGEMM_INTERLEAVE 1   // 1: spread the DMA issue of a K step over its four MFMA groups (compile with -DIGEMM_INTERLEAVE=0 for A/B)
-#endif
-
-#define EPI_R1 1
-#define EPI_R2 2
-#define EPI_RV 4
-#define EPI_GEGLU 8
-
-__device__ __forceinline__ void glds16(const f16* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-// Every wait of the K loop sits right in front of an s_barrier that hands an LDS stage to another writer (the next
-// DMA, the epilogue slabs).  It therefore also drains lgkmcnt: hipcc is free to sink the wait for the wave's last
-// ds_reads (and the MFMAs consuming them) below a raw s_barrier, and a wave that is past the barrier would then
-// overwrite LDS that those reads have not returned from yet.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
-__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // wait until at most t VMEM operations are outstanding, t rounded DOWN to an encodable step (waiting longer is safe)
 __device__ __forceinline__ void wait_vmcnt_le(int t) {
     if (t >= 48) wait_vmcnt<48>();
@@ -193,16 +92,9 @@ __device__ __forceinline__ void bias_touch(f32x4 (&b)[4]) {
 
 // (mrow0, ncol0) = origin of this wave's MI x 2 block of 32x32 accumulator tiles; slab = this wave's LDS slab.
 // WIDE: every row start of out / r1 / r2 is 16-byte aligned and N % 8 == 0 (a piece is whole or empty).
-#ifdef MOFA_IGEMM_TRACE
-#define EPI_TRACE_PARAMS , unsigned long long& tr_t, unsigned long long (&tr_acc)[8]
-#define EPI_TRACE_ARGS , tr_t, tr_acc
-#else
-#define EPI_TRACE_PARAMS
-#define EPI_TRACE_ARGS
-#endif
 template <int MI, int EPI, bool WIDE>
 __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 (&acc)[MI][2], const int mrow0,
-                                               const int ncol0, const int lane, char* slab, f32x4 (&bias)[4] EPI_TRACE_PARAMS) {
+                                               const int ncol0, const int lane, char* slab, f32x4 (&bias)[4]) {
     constexpr bool GEGLU = (EPI & EPI_GEGLU) != 0, R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0,
                    RV = (EPI & EPI_RV) != 0;
     constexpr int CPR = GEGLU ? 4 : 8;          // 8-column pieces per output row of this wave
@@ -270,7 +162,6 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
         }
     };
 
-    TRACE_ADD(4);
     // The three scale factors live in VGPRs on purpose.  As SGPR operands hipcc folds (s_acc, s1) into one SGPR pair
     // feeding v_pk_mul_f32 / v_pk_fma_f32 with op_sel cross terms, and on MI355X (two workgroups per CU) that code
     // intermittently dropped the s1 * r1 term of output column 4 of a piece in lanes 48..63 (tools/igemm_det.hip: 7 of 7
@@ -291,7 +182,6 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
                 *(f32x4*)(slab + slab_off(l31, j * 8 + 2 * q + lh)) = v;
             }
-        TRACE_ADD(5);
         // ---- phase 2: P passes of RPP rows in NG load groups; a lane owns 8 consecutive output columns of one row ----
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -361,7 +251,6 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
                 }
             }
         }
-        TRACE_ADD(6);
     }
 }
 
@@ -380,7 +269,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
     constexpr bool GEGLU = (EPI & EPI_GEGLU) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY shared object: 2 stages
 
-    TRACE_DECL;
     TileWalk walk;
     walk.init(ntiles);
     if (walk.local >= walk.count) return;                          // whole workgroup idle
@@ -497,10 +385,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
             const char* sb = smem + cur * STB;
             char* nb = smem + nxt * STB;
             constexpr int OPS = XI + WI, NG = BKS / 16;      // DMA instructions per stage, MFMA groups per stage
-            constexpr int SPREAD = IGEMM_SPREAD;             // the refill is issued over the first SPREAD MFMA groups
+            constexpr int SPREAD = 4;                        // the refill is issued over all four MFMA groups
 #pragma unroll
             for (int kk = 0; kk < NG; ++kk) {
-#if IGEMM_EXP != 1
 #pragma unroll
                 for (int o = (kk * OPS / SPREAD < OPS ? kk * OPS / SPREAD : OPS);
                      o < ((kk + 1) * OPS / SPREAD < OPS ? (kk + 1) * OPS / SPREAD : OPS); ++o) {
@@ -511,29 +398,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
                         glds16(wsrc[o - XI] + (size_t)ksw * BKS, nb + SXB + (wave * WI + (o - XI)) * 1024);
                     }
                 }
-#endif
-#if IGEMM_EXP == 3
-                (void)sb;
-                continue;                                     // refill + barriers only: no fragment reads, no MFMA
-#endif
                 const int slot = ((kk * 2 + lh) ^ fsw) * 16;
                 f16x8 xf[MI], wf[NJ];
 #pragma unroll
                 for (int i = 0; i < MI; ++i) xf[i] = *(const f16x8*)(sb + xrow + i * 32 * RB + slot);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) wf[j] = *(const f16x8*)(sb + wrow + j * 32 * RB + slot);
-#if IGEMM_EXP == 2
-#pragma unroll
-                for (int i = 0; i < MI; ++i) asm volatile("" ::"v"(xf[i]));
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(wf[j]));
-#else
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-#endif
             }
             ++ksw;
             if (++ikc == kpt) { ikc = 0; ++itap; }
@@ -543,20 +418,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
         for (int ks = 0; ks < nk - 1; ++ks) {
             if (ks == 0) wait_vmcnt_le(allow); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (ks == 0) TRACE_ADD(0);               // bucket 0: waiting for a tile's first stage
             const int cur = (par + ks) & 1;
-#if IGEMM_INTERLEAVE
             compute_and_issue(cur, cur ^ 1);
-#else
-            issue(cur ^ 1);
-            compute(cur);
-#endif
         }
         // last K step (peeled: the set-up of the next tile stays out of the steady-state loop)
         const int last = (par + nk - 1) & 1;
         if (nk == 1) wait_vmcnt_le(allow); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (nk == 1) TRACE_ADD(0);
         bias_touch<EPI>(bias);                            // landed long ago (loaded a tile ahead); see load_bias
         walk.local += walk.stride;
         const bool has_next = walk.local < walk.count;
@@ -572,16 +440,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
         compute(last);
         wait_lds();
         __builtin_amdgcn_s_barrier();                     // every wave is done reading the last stage: it becomes slabs
-        TRACE_ADD(1);
         char* slab = smem + last * STB + wave * EPI_SLAB_BYTES;
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        if (wide) igemm_epilogue<MI, EPI, true>(a, acc, m0c + wm * MI * 32, n0c + wn * NJ * 32, lane_e, slab, bias EPI_TRACE_ARGS);
-        else igemm_epilogue<MI, EPI, false>(a, acc, m0c + wm * MI * 32, n0c + wn * NJ * 32, lane_e, slab, bias EPI_TRACE_ARGS);
-        TRACE_ADD(2);
-#ifdef MOFA_IGEMM_TRACE
-        tr_acc[3] += 1;
-#endif
+        if (wide) igemm_epilogue<MI, EPI, true>(a, acc, m0c + wm * MI * 32, n0c + wn * NJ * 32, lane_e, slab, bias);
+        else igemm_epilogue<MI, EPI, false>(a, acc, m0c + wm * MI * 32, n0c + wn * NJ * 32, lane_e, slab, bias);
         first = false;
         if (!has_next) break;
         // counted wait only when every epilogue memory instruction certainly executed with at least one lane
@@ -596,23 +459,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_f16_kernel(const mofa_i
     // the wave must not retire with an LDS DMA (the last tile's dummy prefetch) in flight: the LDS allocation could be
     // handed to another workgroup while the DMA still writes into it
     wait_vmcnt<0>();
-    TRACE_FLUSH();
 }
-
-#ifdef MOFA_IGEMM_RING3   // experimental 3-stage 256x128 variant: tools only, see the header of the included file
-#include "igemm_ring3.inc"
-static int s_ring3_on = -1;      // -1: read MOFA_IGEMM_CFG (5 = on); tools/igemm_ring3_check.hip flips it between launches
-static bool s_ring3_attr = false;
-#endif
-
-#ifdef MOFA_IGEMM_PC      // experimental producer / consumer 128x128 variant: tools only, see the header of the included file
-#ifndef IGEMM_PC_PROD
-#define IGEMM_PC_PROD 2
-#endif
-#include "igemm_pc.inc"
-static int s_pc_on = -1;         // -1: read MOFA_IGEMM_CFG (6 = on); tools/igemm_pc_check.hip flips it between launches
-static bool s_pc_attr = false;
-#endif
 
 extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (!a || !a->x || !a->w || !a->out) return MOFA_EINVAL;
@@ -634,102 +481,79 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (a->ldx % 8 != 0 || a->ldo % 4 != 0) return MOFA_EINVAL;
     if ((a->r1 && a->ldr1 % 4 != 0) || (a->r2 && a->ldr2 % 4 != 0)) return MOFA_EINVAL;
 
-    // two tile configurations x nine epilogue kinds (bit 0 r1, bit 1 r2, bit 2 row vector; 8 = GEGLU pair)
-    typedef void (*kern_t)(const mofa_igemm_args, const int, const int);
-    struct Cfg { kern_t k[9]; int tm, tn, threads, lds, wg_per_cu; };
+    // three 4-wave / 2-stage configurations x nine epilogue kinds (bit 0 r1, bit 1 r2, bit 2 row vector; 8 = GEGLU pair);
+    // the fourth choice, the phase-pipelined 256x256 tile, lives in igemm8.hip
+    struct Cfg { igemm_kern_t k[9]; int tm, tn, threads, lds, wg_per_cu; };
 #define IGEMM_KINDS(WM, WN, MI)                                                                                        \
     {igemm_f16_kernel<WM, WN, MI, 0>, igemm_f16_kernel<WM, WN, MI, 1>, igemm_f16_kernel<WM, WN, MI, 2>,                \
      igemm_f16_kernel<WM, WN, MI, 3>, igemm_f16_kernel<WM, WN, MI, 4>, igemm_f16_kernel<WM, WN, MI, 5>,                \
      igemm_f16_kernel<WM, WN, MI, 6>, igemm_f16_kernel<WM, WN, MI, 7>, igemm_f16_kernel<WM, WN, MI, 8>}
     static const Cfg cfgs[3] = {
         {IGEMM_KINDS(2, 2, 2), 128, 128, 256, 2 * 256 * 128, 2},   // 128^2 tile, 2 workgroups per CU
-        {IGEMM_KINDS(2, 4, 4), 256, 256, 512, 2 * 512 * 128, 1},   // 256^2 tile, 1 workgroup per CU
+        {IGEMM_KINDS(2, 4, 4), 256, 256, 512, 2 * 512 * 128, 1},   // 256^2 tile, 2-stage loop, 1 workgroup per CU
         {IGEMM_KINDS(2, 2, 3), 192, 128, 256, 2 * 320 * 128, 2},   // 192x128 tile: 2 x 80 KB = the whole LDS of a CU
     };
-    static int variant = -1;   // -1 unset, 0 / 1 / 2 forced configuration (MOFA_IGEMM_CFG=2 / 3 / 4), 100 = auto
+    static int forced = -1;    // -1 unset; MOFA_TILE_* forced for every launch by MOFA_IGEMM_CFG; 0 = none
     static int n_cu = 256;
-    if (variant == -1) {
+    if (forced == -1) {
         const char* e2 = getenv("MOFA_IGEMM_CFG");
-        const int v = e2 ? atoi(e2) : 100;
+        const int v = e2 ? atoi(e2) : 0;
         for (const Cfg& c : cfgs)
-            for (kern_t k : c.k)
+            for (igemm_kern_t k : c.k)
                 if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess)
                     return MOFA_ELAUNCH;
+        if (igemm8_init() != MOFA_OK) return MOFA_ELAUNCH;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             n_cu = cus;
-        variant = (v == 2) ? 0 : (v == 3 ? 1 : (v == 4 ? 2 : 100));
+        forced = (v >= MOFA_TILE_128X128 && v <= MOFA_TILE_256X256) ? v : 0;
     }
+    if (a->tile != 0 && (a->tile < MOFA_TILE_128X128 || a->tile > MOFA_TILE_256X256)) return MOFA_EINVAL;
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const long long Ktot = (long long)taps * a->Cin;
     const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
-    int ci = variant;
-    if (variant == 100) {
+    int choice = a->tile ? a->tile : forced;                  // MOFA_TILE_* or 0 = cost model
+    if (choice == 0) {
         // Tile choice = the cheapest of (rounds of resident workgroups) x (CU time of one round ~ workgroups per CU x tile
         // area x measured relative cost per flop):
-        //   128x128  1.00  two workgroups per CU
-        //   192x128  0.86  two workgroups fill the CU's 160 KB of LDS exactly; 17 % less fill / LDS-read traffic per flop,
-        //                  50 % more MFMA work per barrier (tools/igemm_trace: K step 2450 vs 1950 ticks for 1.5x the work)
-        //   256x256  0.78  one workgroup per CU, half the fill traffic; only where N is wide relative to K (GEGLU / QKV
-        //                  projections: profiles/r01_igemm_config_sweep.md) and the epilogue has no residual loads (registers)
+        //   128x128          1.00  two workgroups per CU
+        //   192x128          0.86  two workgroups fill the CU's 160 KB of LDS exactly; 17 % less fill / LDS-read traffic per
+        //                          flop, 50 % more MFMA work per barrier
+        //   256x256 2-stage  0.78  one workgroup per CU; only where N is wide relative to K and the epilogue has no residual
+        //                          loads (registers)
+        //   256x256 phased   REL8  igemm8.hip (needs 16-byte aligned rows)
         // Rounds count the padding waste of partial tiles and the idle slots of the last round (e.g. M = 7200: 570 tiles of
         // 128x128 need two rounds of 512 slots, 380 tiles of 192x128 one).
         static const double rel[3] = {1.00, 0.78, 0.86};
+        static const int ids[3] = {MOFA_TILE_128X128, MOFA_TILE_256X256_2STAGE, MOFA_TILE_192X128};
         double best = 0;
-        ci = 0;
         for (int k = 0; k < 3; ++k) {
             if (k == 1 && (!(kind == 0 || kind == 8) || (long long)a->N < 2 * Ktot)) continue;
             const long long t = (long long)cdiv(a->M, cfgs[k].tm) * cdiv(a->N, cfgs[k].tn);
             const long long slots_k = (long long)n_cu * cfgs[k].wg_per_cu;
             // a round of co-resident workgroups takes wg_per_cu x (tile area x relative cost) of CU time
             const double cost = (double)((t + slots_k - 1) / slots_k) * cfgs[k].tm * cfgs[k].tn * rel[k] * cfgs[k].wg_per_cu;
-            if (k == 0 || cost < best) { best = cost; ci = k; }
+            if (choice == 0 || cost < best) { best = cost; choice = ids[k]; }
+        }
+        {
+            const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 256);
+            const double cost = (double)((t + n_cu - 1) / n_cu) * 256 * 256 * IGEMM8_REL_COST;
+            if (cost < best) choice = MOFA_TILE_256X256;
         }
     }
-    const Cfg* sel = &cfgs[ci];
-#ifdef MOFA_IGEMM_RING3
-    // MOFA_IGEMM_CFG=5: the experimental 3-stage 256x128 kernel (needs >= 4 K steps), otherwise the normal choice
-    static const Cfg ring3 = {{igemm3_f16_kernel<4, 2, 2, 0>, igemm3_f16_kernel<4, 2, 2, 1>, igemm3_f16_kernel<4, 2, 2, 2>,
-                               igemm3_f16_kernel<4, 2, 2, 3>, igemm3_f16_kernel<4, 2, 2, 4>, igemm3_f16_kernel<4, 2, 2, 5>,
-                               igemm3_f16_kernel<4, 2, 2, 6>, igemm3_f16_kernel<4, 2, 2, 7>, igemm3_f16_kernel<4, 2, 2, 8>},
-                              256, 128, 512, 3 * 384 * 128 + 2 * EPI_SLAB_BYTES, 1};
-    if (s_ring3_on < 0) {
-        const char* e5 = getenv("MOFA_IGEMM_CFG");
-        s_ring3_on = (e5 && atoi(e5) == 5) ? 1 : 0;
+    if (choice == MOFA_TILE_256X256) {
+        const int rc = igemm8_launch(a, kind, n_cu, (hipStream_t)stream);
+        if (rc <= 0) return rc;                               // launched (0) or failed (< 0)
+        if (a->tile == MOFA_TILE_256X256) return MOFA_EINVAL; // explicitly requested but not eligible (alignment)
+        choice = MOFA_TILE_192X128;                           // forced by environment / chosen by the model: fall back
     }
-    if (s_ring3_on == 1 && !s_ring3_attr) {
-        for (kern_t k : ring3.k)
-            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, ring3.lds) != hipSuccess)
-                return MOFA_ELAUNCH;
-        s_ring3_attr = true;
-    }
-    if (s_ring3_on == 1 && Ktot / 64 >= 4) sel = &ring3;
-#endif
-#ifdef MOFA_IGEMM_PC
-    // MOFA_IGEMM_CFG=6: the experimental producer / consumer kernel for the plain, r1 and GEGLU epilogue kinds
-    static const Cfg pc = {{igemm_pc_f16_kernel<0, IGEMM_PC_PROD>, igemm_pc_f16_kernel<1, IGEMM_PC_PROD>, nullptr, nullptr, nullptr,
-                            nullptr, nullptr, nullptr, igemm_pc_f16_kernel<8, IGEMM_PC_PROD>},
-                           128, 128, 64 * (4 + IGEMM_PC_PROD), 2 * 256 * 128, 2};
-    if (s_pc_on < 0) {
-        const char* e6 = getenv("MOFA_IGEMM_CFG");
-        s_pc_on = (e6 && atoi(e6) == 6) ? 1 : 0;
-    }
-    if (s_pc_on == 1 && !s_pc_attr) {
-        for (kern_t k : pc.k)
-            if (k && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, pc.lds) != hipSuccess)
-                return MOFA_ELAUNCH;
-        s_pc_attr = true;
-    }
-    if (s_pc_on == 1 && pc.k[kind]) sel = &pc;
-#endif
+    const Cfg* sel = &cfgs[choice == MOFA_TILE_128X128 ? 0 : (choice == MOFA_TILE_256X256_2STAGE ? 1 : 2)];
     const Cfg& c = *sel;
     const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
     const long long nt = (long long)tilesM * tilesN;
     if (nt > 0x7fffffffLL) return MOFA_EINVAL;
-    static int persist = -1;
-    if (persist < 0) { const char* e = getenv("MOFA_IGEMM_PERSIST"); persist = e ? atoi(e) : 1; }
-    const int slots = persist > 0 ? n_cu * c.wg_per_cu * persist : 0x7ffffff8;   // resident workgroups (a multiple of 8 on gfx950)
+    const int slots = n_cu * c.wg_per_cu;                     // resident workgroups (a multiple of 8 on gfx950)
     int grid = (int)(nt < slots ? ((nt + 7) / 8) * 8 : (slots / 8) * 8);
     if (grid < 8) grid = 8;
     hipLaunchKernelGGL(c.k[kind], dim3(grid), dim3(c.threads), c.lds, (hipStream_t)stream, *a, tilesN, (int)nt);

@@ -61,6 +61,7 @@ class LaunchTimer:
 
 
 TIMER = None
+FORCE_TILE = L.TILE_AUTO     # tests set this to run whole models through one igemm tile (lib.TILE_*)
 
 
 def _ld(t):
@@ -104,8 +105,9 @@ def convt3_geom(T, HW):
 
 
 def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, r2=None, s2=1.0,
-          act=L.ACT_NONE, s_acc=1.0, out=None):
-    """out[m,n] = act(s_acc*(conv/gemm + bias + rowvec[idx(m)]) + s1*r1 + s2*r2).  See include/mofa_hip.h."""
+          act=L.ACT_NONE, s_acc=1.0, out=None, tile=None):
+    """out[m,n] = act(s_acc*(conv/gemm + bias + rowvec[idx(m)]) + s1*r1 + s2*r2).  See include/mofa_hip.h.
+    tile: one of lib.TILE_* to force the output tile (parity tests); default = ops.FORCE_TILE = the launcher's model."""
     lib = L.load()
     _chk(x, F16); _chk(w, F16)
     N, Ktot = w.shape
@@ -155,6 +157,7 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     a.rv_div, a.rv_mul, a.rv_mod_in, a.rv_mod_out = rv
     a.act = act
     a.s_acc, a.s1, a.s2 = s_acc, s1, s2
+    a.tile = FORCE_TILE if tile is None else tile
     t0 = TIMER.start() if TIMER is not None else None
     L.check(lib.mofa_igemm_f16(C.byref(a), L.stream_ptr()), "mofa_igemm_f16")
     if t0 is not None:
