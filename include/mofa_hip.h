@@ -81,10 +81,10 @@ typedef struct mofa_igemm_args {
                          * forces it (parity tests run every shape through every tile).  sizeof(mofa_igemm_args) = 168 */
 } mofa_igemm_args;
 enum { MOFA_PAD_SAME = 0, MOFA_PAD_TRAILING = 1 };
-/* output tiles of the implicit GEMM: 4 waves / 2 workgroups per CU (128x128, 192x128), 8 waves / 1 per CU with the
- * 2-stage K loop (256x256), and the 8-wave phase-pipelined 256x256 tile the denoise loop mostly runs on (needs 16-byte
- * aligned rows: MOFA_EINVAL if forced on an ineligible call) */
-enum { MOFA_TILE_AUTO = 0, MOFA_TILE_128X128 = 2, MOFA_TILE_256X256_2STAGE = 3, MOFA_TILE_192X128 = 4, MOFA_TILE_256X256 = 5 };
+/* output tiles of the implicit GEMM: 4 waves / 2 workgroups per CU (128x128, 192x128) and the 8-wave phase-pipelined
+ * 256x256 tile (needs 16-byte aligned rows and no activation on residual kinds: MOFA_EINVAL if forced on an ineligible
+ * call) */
+enum { MOFA_TILE_AUTO = 0, MOFA_TILE_128X128 = 2, MOFA_TILE_192X128 = 4, MOFA_TILE_256X256 = 5 };
 
 int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
 

@@ -4,8 +4,8 @@
 //   out[m, n] = act( s_acc * (sum_tap sum_k X[src(m,tap), k] * W[n, tap*Cin + k] + bias[n] + rowvec[idx(m), n])
 //                    + s1 * R1[m, n] + s2 * R2[m, n] )
 //
-// One PERSISTENT workgroup per CU slot walks output tiles (128x128 or 192x128 with 4 waves, 2 workgroups per CU; or
-// 256x256 with 8 waves, 1 per CU; the launcher picks by a small cost model).  Each wave owns MI x 2 MFMA 32x32x16 f16
+// One PERSISTENT workgroup per CU slot walks output tiles (128x128 or 192x128 with 4 waves, 2 workgroups per CU; the
+// 8-wave 256x256 tile is igemm8.hip; the launcher picks by a small cost model).  Each wave owns MI x 2 MFMA 32x32x16 f16
 // tiles with fp32 accumulators.  The MFMA "A" operand is
 // the WEIGHT tile and the "B" operand the ACTIVATION tile, so an accumulator lane owns one output row.  K is walked
 // tap-major in steps of 64 (128-byte LDS rows = whole cache lines per row); zero padding of the convolution is realised
@@ -27,17 +27,14 @@
 // in order on gfx9: a load issued before a store never waits for it).  The kernel is templated on the epilogue kind
 // (residuals / row vector / GEGLU) so the memory operations per pass are static.
 // Tile choice: mofa_igemm_args.tile (MOFA_TILE_*; 0 = the launcher's cost model); the environment variable
-// MOFA_IGEMM_CFG=2|3|4|5 forces the 128x128 | 256x256 (this file's 2-stage loop) | 192x128 | 256x256 phase-pipelined
-// (igemm8.hip) tile for every launch that leaves `tile` at 0.
+// MOFA_IGEMM_CFG=2|4|5 forces the 128x128 | 192x128 | 256x256 phase-pipelined (igemm8.hip) tile for every launch that
+// leaves `tile` at 0.
 // Earlier variants (register staging, 64-byte rows, deeper rings, 256x128 tiles) and their measurements:
 // profiles/r01_igemm_config_sweep.md.
 #include <stdlib.h>
 
 #include "igemm_common.h"
 
-#ifndef IGEMM8_REL_COST
-#define IGEMM8_REL_COST 0.60   // relative cost per flop of the phase-pipelined 256x256 tile (see the cost model below)
-#endif
 
 // wait until at most t VMEM operations are outstanding, t rounded DOWN to an encodable step (waiting longer is safe)
 __device__ __forceinline__ void wait_vmcnt_le(int t) {
@@ -481,16 +478,15 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (a->ldx % 8 != 0 || a->ldo % 4 != 0) return MOFA_EINVAL;
     if ((a->r1 && a->ldr1 % 4 != 0) || (a->r2 && a->ldr2 % 4 != 0)) return MOFA_EINVAL;
 
-    // three 4-wave / 2-stage configurations x nine epilogue kinds (bit 0 r1, bit 1 r2, bit 2 row vector; 8 = GEGLU pair);
-    // the fourth choice, the phase-pipelined 256x256 tile, lives in igemm8.hip
+    // two 4-wave configurations x nine epilogue kinds (bit 0 r1, bit 1 r2, bit 2 row vector; 8 = GEGLU pair); the third
+    // choice, the 8-wave phase-pipelined 256x256 tile, lives in igemm8.hip
     struct Cfg { igemm_kern_t k[9]; int tm, tn, threads, lds, wg_per_cu; };
 #define IGEMM_KINDS(WM, WN, MI)                                                                                        \
     {igemm_f16_kernel<WM, WN, MI, 0>, igemm_f16_kernel<WM, WN, MI, 1>, igemm_f16_kernel<WM, WN, MI, 2>,                \
      igemm_f16_kernel<WM, WN, MI, 3>, igemm_f16_kernel<WM, WN, MI, 4>, igemm_f16_kernel<WM, WN, MI, 5>,                \
      igemm_f16_kernel<WM, WN, MI, 6>, igemm_f16_kernel<WM, WN, MI, 7>, igemm_f16_kernel<WM, WN, MI, 8>}
-    static const Cfg cfgs[3] = {
+    static const Cfg cfgs[2] = {
         {IGEMM_KINDS(2, 2, 2), 128, 128, 256, 2 * 256 * 128, 2},   // 128^2 tile, 2 workgroups per CU
-        {IGEMM_KINDS(2, 4, 4), 256, 256, 512, 2 * 512 * 128, 1},   // 256^2 tile, 2-stage loop, 1 workgroup per CU
         {IGEMM_KINDS(2, 2, 3), 192, 128, 256, 2 * 320 * 128, 2},   // 192x128 tile: 2 x 80 KB = the whole LDS of a CU
     };
     static int forced = -1;    // -1 unset; MOFA_TILE_* forced for every launch by MOFA_IGEMM_CFG; 0 = none
@@ -507,38 +503,42 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             n_cu = cus;
-        forced = (v >= MOFA_TILE_128X128 && v <= MOFA_TILE_256X256) ? v : 0;
+        forced = (v == MOFA_TILE_128X128 || v == MOFA_TILE_192X128 || v == MOFA_TILE_256X256) ? v : 0;
     }
-    if (a->tile != 0 && (a->tile < MOFA_TILE_128X128 || a->tile > MOFA_TILE_256X256)) return MOFA_EINVAL;
+    if (a->tile != 0 && a->tile != MOFA_TILE_128X128 && a->tile != MOFA_TILE_192X128 && a->tile != MOFA_TILE_256X256)
+        return MOFA_EINVAL;
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const long long Ktot = (long long)taps * a->Cin;
     const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
     int choice = a->tile ? a->tile : forced;                  // MOFA_TILE_* or 0 = cost model
     if (choice == 0) {
-        // Tile choice = the cheapest of (rounds of resident workgroups) x (CU time of one round ~ workgroups per CU x tile
-        // area x measured relative cost per flop):
-        //   128x128          1.00  two workgroups per CU
-        //   192x128          0.86  two workgroups fill the CU's 160 KB of LDS exactly; 17 % less fill / LDS-read traffic per
-        //                          flop, 50 % more MFMA work per barrier
-        //   256x256 2-stage  0.78  one workgroup per CU; only where N is wide relative to K and the epilogue has no residual
-        //                          loads (registers)
-        //   256x256 phased   REL8  igemm8.hip (needs 16-byte aligned rows)
-        // Rounds count the padding waste of partial tiles and the idle slots of the last round (e.g. M = 7200: 570 tiles of
-        // 128x128 need two rounds of 512 slots, 380 tiles of 192x128 one).
-        static const double rel[3] = {1.00, 0.78, 0.86};
-        static const int ids[3] = {MOFA_TILE_128X128, MOFA_TILE_256X256_2STAGE, MOFA_TILE_192X128};
+        // Tile choice = the cheapest of  rounds of resident workgroups x CU time of one round, the latter modelled as
+        //   workgroups per CU x tile area x relative K-loop cost per flop x (1 + epilogue / K loop),  epilogue in K tiles:
+        //     128x128   1.00   two workgroups per CU
+        //     192x128   0.86   two workgroups fill the CU's 160 KB of LDS exactly; 17 % less fill / LDS-read traffic per
+        //                      flop, 50 % more MFMA work per barrier
+        //     256x256   0.62   8 waves, phase-pipelined K loop (igemm8.hip; needs 16-byte aligned rows)
+        // fitted to tools/igemm_tiles_bench.py on the denoise step's shapes (profiles/r02_igemm_tiles.md).  Rounds count the
+        // padding waste of partial tiles and the idle slots of the last round (e.g. N = 320: 2 x 256 wastes 37 %, 3 x 128
+        // 17 %; M = 7200: 570 tiles of 128x128 need two rounds of 512 slots, 380 tiles of 192x128 one).
+        static const double rel[2] = {1.00, 0.86};
+        static const int ids[2] = {MOFA_TILE_128X128, MOFA_TILE_192X128};
+        // epilogue cost in K tiles per epilogue kind (index = kind): 4-wave tiles (their epilogue overlaps the co-resident
+        // workgroup's K loop) / the 8-wave tile
+        static const double epi4[9] = {2.0, 3.5, 4.0, 4.0, 3.5, 4.0, 4.5, 4.5, 4.0};
+        static const double epi8[9] = {2.2, 5.2, 5.2, 6.0, 7.0, 7.0, 7.0, 7.5, 3.3};
+        const double nk = (double)(Ktot / 64);
         double best = 0;
-        for (int k = 0; k < 3; ++k) {
-            if (k == 1 && (!(kind == 0 || kind == 8) || (long long)a->N < 2 * Ktot)) continue;
+        for (int k = 0; k < 2; ++k) {
             const long long t = (long long)cdiv(a->M, cfgs[k].tm) * cdiv(a->N, cfgs[k].tn);
             const long long slots_k = (long long)n_cu * cfgs[k].wg_per_cu;
-            // a round of co-resident workgroups takes wg_per_cu x (tile area x relative cost) of CU time
-            const double cost = (double)((t + slots_k - 1) / slots_k) * cfgs[k].tm * cfgs[k].tn * rel[k] * cfgs[k].wg_per_cu;
+            const double cost = (double)((t + slots_k - 1) / slots_k) * cfgs[k].tm * cfgs[k].tn * rel[k] * cfgs[k].wg_per_cu *
+                                (1.0 + epi4[kind] / nk);
             if (choice == 0 || cost < best) { best = cost; choice = ids[k]; }
         }
         {
             const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 256);
-            const double cost = (double)((t + n_cu - 1) / n_cu) * 256 * 256 * IGEMM8_REL_COST;
+            const double cost = (double)((t + n_cu - 1) / n_cu) * 256 * 256 * 0.62 * (1.0 + epi8[kind] / nk);
             if (cost < best) choice = MOFA_TILE_256X256;
         }
     }
@@ -548,7 +548,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (a->tile == MOFA_TILE_256X256) return MOFA_EINVAL; // explicitly requested but not eligible (alignment)
         choice = MOFA_TILE_192X128;                           // forced by environment / chosen by the model: fall back
     }
-    const Cfg* sel = &cfgs[choice == MOFA_TILE_128X128 ? 0 : (choice == MOFA_TILE_256X256_2STAGE ? 1 : 2)];
+    const Cfg* sel = &cfgs[choice == MOFA_TILE_128X128 ? 0 : 1];
     const Cfg& c = *sel;
     const int tilesM = cdiv(a->M, c.tm), tilesN = cdiv(a->N, c.tn);
     const long long nt = (long long)tilesM * tilesN;

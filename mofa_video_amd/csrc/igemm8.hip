@@ -46,7 +46,7 @@ constexpr int BKS = 64, RB = 128;                              // K per tile, LD
 constexpr int SXB = TBM * RB, STB = SXB + TBN * RB;            // bytes: X part, one K tile of the ring
 constexpr int SCRATCH0 = 2 * STB, SCRATCH_WAVE = 4096;
 constexpr int LDS_BYTES = SCRATCH0 + 8 * SCRATCH_WAVE;         // 163840 = the CU's whole LDS
-constexpr int LOOKAHEAD_OPS = 8;                               // DMA instructions of the last 4 phases may be in flight
+constexpr int LOOKAHEAD_OPS = 8;                               // DMA instructions of the last 2 phases may be in flight
 
 // epilogue scratch images (tools/lds_bank_sim.py)
 __device__ __forceinline__ int h16_off(int r, int c8) {        // 32 rows x 64 fp16; c8 = 8-byte chunk (4 columns)
@@ -63,26 +63,38 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv d) { return d.mul ? (in
 
 struct Aux {                        // launch-invariant scalars computed by the launcher
     FastDiv tiles_n, hw, wout, t3hw, t3t;
-    int ldx16;                      // activation row stride in 16-byte units
-    const f16* zero;                // the zero page (as an argument: addressing the symbol costs an s_load through the
-};                                  // GOT at every use, and its lgkmcnt(0) wait also drains the fragment reads in flight)
+    int ldxb;                       // activation row stride in bytes
+    int row_shift;                  // rows between xbase and a.x (convT3 with caller-supplied halo frames: HW, else 0)
+    const void* xbase;              // base of the activation buffer descriptor
+    unsigned x_bytes, w_bytes;      // extents of the two buffer descriptors
+    unsigned long long* trace;      // VAR & 64: [workgroup][group][16] cycle sums
+};
 
 // One DMA row group = ONE packed register (Cursor::gx), decoded at every tap switch:
 //   plain    m                                         conv     img << 20 | oy << 10 | ox
 //   convT3   m | (frame > 0 or unclipped) << 29 | (frame < T - 1 or unclipped) << 30
 //   -1       row beyond M
-constexpr int XO_INVALID = (int)0x80000000;
+// DMA sources are addressed through BUFFER descriptors (buffer_load_dwordx4 ... lds): a 32-bit byte offset per lane, the
+// K offset in an SGPR, no 64-bit address arithmetic -- and an offset beyond the descriptor's extent reads as ZERO, which
+// is how rows of an out-of-image tap / beyond M / past the end of the tile walk are sourced (no zero page, no select).
+constexpr unsigned XO_INVALID = 0xffffffffu;
+
+template <int V> struct IC { static constexpr int v = V; };
 
 struct Cursor {                     // one half-tile pair (X half h, W half h) of the persistent K-tile stream
     int local;                      // walk position of the output tile it is in
     int ikc, ksw, ky, kx;           // K tile within the tap / overall, tap coordinates (convT3: ky = tap)
-    bool live;                      // false past the end of the walk: every source is the zero page
-    int gx[2];                      // packed row geometry
-    int xo[2];                      // source row of the current tap, 16-byte units from a.x (XO_INVALID = zero page)
-    unsigned wo[2];                 // weight row + this lane's swizzled chunk, bytes from a.w
+    // per DMA piece (named scalars, not arrays: hipcc otherwise keeps part of the struct in scratch memory)
+    int gx0, gx1;                   // packed row geometry
+    unsigned xo0, xo1;              // source row of the current tap + this lane's swizzled chunk, bytes from aux.xbase
+    unsigned wo0, wo1, wo2, wo3;    // (W stream only) weight row + this lane's swizzled chunk, bytes from a.w
 };
 
-template <int EPI>
+// VAR: diagnostic build variants of the K loop (tools/igemm8_probe.py; the library's launches use VAR = 0):
+//   1 no stagger between the wave groups   2 no s_setprio   4 DMA issue before the fragment reads   8 no vmcnt wait
+//   16 no DMA inside the loop   32 no fragment reads inside the loop   64 per-segment cycle trace into aux.trace
+// (8, 16, 32 give wrong results: timing probes only)
+template <int EPI, int VAR = 0>
 __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_args a, const int tilesN, const int ntiles,
                                                             const Aux aux) {
     constexpr bool GEGLU = (EPI & EPI_GEGLU) != 0, R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0,
@@ -105,114 +117,376 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
     // piece q (8 rows x 128 B, one DMA instruction) of half h: half-local row hr = 16 wave + 8 q + lane / 8;
     // X tile row = (hr / 64) * 128 + h * 64 + hr % 64, W tile row = (hr / 32) * 64 + h * 32 + hr % 32; the 16-byte slot
     // lane % 8 of a row holds source chunk slot ^ ((row >> 1) & 7) = slot ^ (4 q + lane / 16)
-    const int hr_l = 16 * wave + (lane >> 3);
-    int swz_e[2];                                                  // element offset of this lane's chunk, per piece
-    swz_e[0] = ((lane & 7) ^ (lane >> 4)) * 8;
-    swz_e[1] = ((lane & 7) ^ (4 + (lane >> 4))) * 8;
-    auto x_row = [&](int h, int q, int hr0) { const int hr = hr0 + 8 * q; return (hr >> 6) * 128 + h * 64 + (hr & 63); };
-    auto w_row = [&](int h, int q, int hr0) { const int hr = hr0 + 8 * q; return (hr >> 5) * 64 + h * 32 + (hr & 31); };
+    // (lane-derived values are recomputed where they are used -- per tap / per tile -- instead of living in VGPRs)
+    auto lane_now = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto swz_bytes = [&](int l, int q) __attribute__((always_inline)) { return (((l & 7) ^ (4 * q + (l >> 4))) * 16); };
+    auto x_row = [&](int h, int q, int hr0) __attribute__((always_inline)) { const int hr = hr0 + 8 * q; return (hr >> 6) * 128 + h * 64 + (hr & 63); };
+    auto w_row = [&](int h, int q, int hr0) __attribute__((always_inline)) { const int hr = hr0 + 8 * q; return (hr >> 5) * 64 + h * 32 + (hr & 31); };
     const int ks_ = a.ksize > 0 ? a.ksize : 3, dil_ = a.dil > 0 ? a.dil : 1;
     const int org_ = a.pad == MOFA_PAD_TRAILING ? 0 : (ks_ >> 1);
-    auto pack_geo = [&](int m) -> int {
-        if (m >= a.M) return -1;
+    // (single-exit lambdas: with several return statements hipcc leaves the result slots in scratch memory)
+    auto pack_geo = [&](int m) __attribute__((always_inline)) -> int {
+        int g = m;
         if (a.mode == MOFA_MODE_CONV3X3) {
             const int img = fdiv(m, aux.hw), rem = m - img * (a.Hout * a.Wout);
             const int oy = fdiv(rem, aux.wout);
-            return (img << 20) | (oy << 10) | (rem - oy * a.Wout);
-        }
-        if (a.mode == MOFA_MODE_CONVT3) {
+            g = (img << 20) | (oy << 10) | (rem - oy * a.Wout);
+        } else if (a.mode == MOFA_MODE_CONVT3) {
             int lo = 1, hi = 1;
             if (a.T > 0) {
                 const int fr = fdiv(m, aux.t3hw);                  // frame index; its position within the clip of T
                 const int f = fr - fdiv(fr, aux.t3t) * a.T;
                 lo = f > 0; hi = f < a.T - 1;
             }
-            return m | (lo << 29) | (hi << 30);
+            g = m | (lo << 29) | (hi << 30);
         }
-        return m;
+        return m < a.M ? g : -1;
     };
-    auto tap_src = [&](int g, int ky, int kx) -> int {            // 16-byte units from a.x, or XO_INVALID
-        if (g < 0) return XO_INVALID;
-        if (a.mode == MOFA_MODE_PLAIN) return g * aux.ldx16;
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)aux.xbase, 0, aux.x_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, aux.w_bytes, 0x00020000);
+    auto bglds16 = [&](const decltype(rsx)& rs, unsigned voff, int soff, char* lds_wave_base) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+    };
+    auto tap_src = [&](int g, int ky, int kx, int swzb) __attribute__((always_inline)) -> unsigned {   // bytes from aux.xbase
+        int row = g;                                               // plain: the output row itself
+        bool ok = g >= 0;
         if (a.mode == MOFA_MODE_CONV3X3) {
             const int vy = ((g >> 10) & 1023) * a.stride + (ky - org_) * dil_;
             const int vx = (g & 1023) * a.stride + (kx - org_) * dil_;
-            if (vy < 0 || vx < 0 || vy >= a.Hin * a.up || vx >= a.Win * a.up) return XO_INVALID;
+            ok = ok && vy >= 0 && vx >= 0 && vy < a.Hin * a.up && vx < a.Win * a.up;
             const int iy = (a.up == 2) ? (vy >> 1) : vy, ix = (a.up == 2) ? (vx >> 1) : vx;
-            return (((g >> 20) * a.Hin + iy) * a.Win + ix) * aux.ldx16;
+            row = ((g >> 20) * a.Hin + iy) * a.Win + ix;
+        } else if (a.mode == MOFA_MODE_CONVT3) {                   // tap ky - 1 frames away
+            ok = ok && !(ky == 0 && !((g >> 29) & 1)) && !(ky == 2 && !((g >> 30) & 1));
+            row = (g & 0x1fffffff) + (ky - 1) * a.HW + aux.row_shift;
         }
-        const int m = g & 0x1fffffff;                              // convT3: tap ky - 1 frames away
-        if ((ky == 0 && !((g >> 29) & 1)) || (ky == 2 && !((g >> 30) & 1))) return XO_INVALID;
-        return (m + (ky - 1) * a.HW) * aux.ldx16;
+        const unsigned off = (unsigned)row * (unsigned)aux.ldxb + (unsigned)swzb;
+        return ok ? off : XO_INVALID;
     };
-    auto cur_setup = [&](Cursor& c, const int h) {
-        c.live = c.local < walk.count;
-        if (c.live) {
-            const int tile = walk.start + c.local;
-            const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                c.gx[q] = pack_geo(tm * TBM + x_row(h, q, hr_l));
-                int n = tn * TBN + w_row(h, q, hr_l);
+    auto cur_setup = [&](Cursor& c, const int h, const bool with_w) __attribute__((always_inline)) {
+        // branch-free on purpose (selects on the uniform `live`): stores to the cursor's fields from two arms of an
+        // if / else get merged into a store through a pointer phi, which pins those fields to scratch memory
+        const bool live = c.local < walk.count;
+        const int tile = walk.start + (live ? c.local : 0);
+        const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
+        const int l = lane_now(), hr_l = 16 * wave + (l >> 3);
+        const int g0 = pack_geo(tm * TBM + x_row(h, 0, hr_l)), g1 = pack_geo(tm * TBM + x_row(h, 1, hr_l));
+        c.gx0 = live ? g0 : -1;
+        c.gx1 = live ? g1 : -1;
+        if (with_w) {
+            auto w_off = [&](int hq) __attribute__((always_inline)) {
+                int n = tn * TBN + w_row(hq >> 1, hq & 1, hr_l);
                 n = n < a.N ? n : a.N - 1;
-                c.wo[q] = (unsigned)n * (unsigned)(Ktot * 2) + swz_e[q] * 2;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { c.gx[q] = -1; c.wo[q] = swz_e[q] * 2; }
+                const unsigned o = (unsigned)n * (unsigned)(Ktot * 2) + swz_bytes(l, hq & 1);
+                return live ? o : XO_INVALID;
+            };
+            c.wo0 = w_off(0); c.wo1 = w_off(1); c.wo2 = w_off(2); c.wo3 = w_off(3);
         }
         c.ikc = 0; c.ksw = 0; c.ky = 0; c.kx = 0;
     };
-    auto issue_x = [&](Cursor& c, const int h, const int bo) {
+    auto issue_x = [&](Cursor& c, const int h, const int bo) __attribute__((always_inline)) {
         if (c.ikc == 0) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) c.xo[q] = tap_src(c.gx[q], c.ky, c.kx);
+            const int l = lane_now();
+            c.xo0 = tap_src(c.gx0, c.ky, c.kx, swz_bytes(l, 0));
+            c.xo1 = tap_src(c.gx1, c.ky, c.kx, swz_bytes(l, 1));
         }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const char* s = (const char*)a.x + ((long long)(c.xo[q] + c.ikc * 8 + (swz_e[q] >> 3)) << 4);
-            if (c.xo[q] == XO_INVALID) s = (const char*)aux.zero;
-            glds16((const f16*)s, smem + bo + x_row(h, q, 16 * wave) * RB);
-        }
+        bglds16(rsx, c.xo0, c.ikc * (BKS * 2), smem + bo + x_row(h, 0, 16 * wave) * RB);
+        bglds16(rsx, c.xo1, c.ikc * (BKS * 2), smem + bo + x_row(h, 1, 16 * wave) * RB);
     };
-    auto issue_w = [&](Cursor& c, const int h, const int bo) {
-        const char* base = c.live ? (const char*)a.w + (size_t)c.ksw * (BKS * 2) : (const char*)aux.zero;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) glds16((const f16*)(base + c.wo[q]), smem + bo + SXB + w_row(h, q, 16 * wave) * RB);
+    auto issue_w = [&](Cursor& c, const int bo) __attribute__((always_inline)) {                  // both W halves: 4 pieces
+        bglds16(rsw, c.wo0, c.ksw * (BKS * 2), smem + bo + SXB + w_row(0, 0, 16 * wave) * RB);
+        bglds16(rsw, c.wo1, c.ksw * (BKS * 2), smem + bo + SXB + w_row(0, 1, 16 * wave) * RB);
+        bglds16(rsw, c.wo2, c.ksw * (BKS * 2), smem + bo + SXB + w_row(1, 0, 16 * wave) * RB);
+        bglds16(rsw, c.wo3, c.ksw * (BKS * 2), smem + bo + SXB + w_row(1, 1, 16 * wave) * RB);
     };
-    auto advance = [&](Cursor& c, const int h) {
+    auto advance = [&](Cursor& c, const int h, const bool with_w) __attribute__((always_inline)) {
         ++c.ksw;
         if (++c.ikc == kpt) {
             c.ikc = 0;
             if (a.mode == MOFA_MODE_CONV3X3) { if (++c.kx == ks_) { c.kx = 0; ++c.ky; } } else ++c.ky;
         }
-        if (c.ksw == nk) { c.local += walk.stride; cur_setup(c, h); }
+        if (c.ksw == nk) { c.local += walk.stride; cur_setup(c, h, with_w); }
     };
 
     // ---- consumer side ----------------------------------------------------------------------------------------------
-    const int fsw = (l31 >> 1) & 7;
-    const int xfrag = (wm * MI * 32 + l31) * RB;                   // byte offsets of this lane's fragment rows
-    const int wfrag = SXB + (wn * NJ * 32 + l31) * RB;
-    int slot[4];
+    // fragment read addresses of ring slot 0 (one register per 16-deep K step; accumulator tile / ring slot 1 are
+    // immediates / a flipped bit 16)
+    int xa[4], wa[4];
+    {
+        const int fsw = (l31 >> 1) & 7;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) slot[kk] = ((kk * 2 + lh) ^ fsw) * 16;
+        for (int kk = 0; kk < 4; ++kk) {
+            const int slot = ((kk * 2 + lh) ^ fsw) * 16;
+            xa[kk] = (wm * MI * 32 + l31) * RB + slot;
+            wa[kk] = SXB + (wn * NJ * 32 + l31) * RB + slot;
+        }
+    }
 
-    Cursor ca, cb;                                                 // (X0, W0) stream, (X1, W1) stream
+    Cursor ca, cb;                                                 // (X0, W0, W1) stream, X1 stream
     ca.local = cb.local = walk.local;
-    cur_setup(ca, 0);
-    cur_setup(cb, 1);
-    // prologue: K tile 0 complete, (X0, W0) of K tile 1
-    issue_x(ca, 0, 0); issue_w(ca, 0, 0); advance(ca, 0);
-    issue_w(cb, 1, 0); issue_x(cb, 1, 0); advance(cb, 1);
-    issue_x(ca, 0, STB); issue_w(ca, 0, STB); advance(ca, 0);
-    wait_vmcnt_only<LOOKAHEAD_OPS>();                              // X0, W0 of K tile 0 have landed
+    cur_setup(ca, 0, true);
+    cur_setup(cb, 1, false);
+    // prologue: K tile 0 complete, (X0, W) of K tile 1: 6 + 2 + 6 DMA instructions
+    issue_x(ca, 0, 0); issue_w(ca, 0); advance(ca, 0, true);
+    issue_x(cb, 1, 0); advance(cb, 1, false);
+    issue_x(ca, 0, STB); issue_w(ca, STB); advance(ca, 0, true);
+    wait_vmcnt_only<LOOKAHEAD_OPS>();                              // X0, W of K tile 0 have landed
     __builtin_amdgcn_s_barrier();
+
+    // ---- one phase of a K tile: {fragment reads, DMA, counted wait} barrier {16 MFMAs on 4 accumulators} barrier
+    f32x16 acc[MI][NJ];
+    f16x8 xf[2][4], wf[2][4];
+    unsigned long long tr[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tr_t = 0;
+    if (VAR & 64) tr_t = __builtin_readcyclecounter();
+    if (VAR & 32) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            xf[0][kk] = *(const f16x8*)(smem + xa[kk]);
+            xf[1][kk] = *(const f16x8*)(smem + xa[kk] + 32 * RB);
+            wf[0][kk] = *(const f16x8*)(smem + wa[kk]);
+            wf[1][kk] = *(const f16x8*)(smem + wa[kk] + 32 * RB);
+        }
+    }
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if (VAR & 64) { const unsigned long long t = __builtin_readcyclecounter(); tr[k] += t - tr_t; tr_t = t; }
+    };
+    auto phase = [&](auto pc, const int bo, const int bn) __attribute__((always_inline)) {
+        constexpr int P = decltype(pc)::v;                         // 1: X half 0 x W, 2: X half 1 x W
+        auto reads = [&]() __attribute__((always_inline)) {
+            if (VAR & 32) return;
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    xf[il][kk] = *(const f16x8*)(smem + xa[kk] + ((P == 2 ? 2 : 0) + il) * 32 * RB);
+            if constexpr (P == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) wf[j][kk] = *(const f16x8*)(smem + wa[kk] + j * 32 * RB);
+            }
+        };
+        auto issues = [&]() __attribute__((always_inline)) {
+            if (VAR & 16) return;
+            if constexpr (P == 1) issue_x(cb, 1, bn);              // X1 of the next K tile
+            if constexpr (P == 2) { issue_x(ca, 0, bo); issue_w(ca, bo); }   // X0, W0, W1 of the K tile after it
+        };
+        if (VAR & 4) { issues(); __builtin_amdgcn_sched_barrier(0); reads(); }
+        else { reads(); __builtin_amdgcn_sched_barrier(0); issues(); }
+        if constexpr (P == 1) advance(cb, 1, false);
+        if constexpr (P == 2) advance(ca, 0, true);
+        // DMA older than the last two phases has landed (read from the next phase on); this phase's fragment reads have
+        // returned BEFORE the barrier, so their LDS rows may be refilled from the next phase on
+        if (!(VAR & 8)) wait_vmcnt<LOOKAHEAD_OPS>(); else wait_lds();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(3 * (P - 1));
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int il = 0; il < 2; ++il)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    constexpr int I0 = (P == 2) ? 2 : 0;
+                    acc[I0 + il][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][kk], xf[il][kk], acc[I0 + il][j], 0, 0, 0);
+                }
+        if (!(VAR & 2)) __builtin_amdgcn_s_setprio(0);
+        stamp(3 * (P - 1) + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(3 * (P - 1) + 2);
+    };
+
+    // ---- epilogue pieces -------------------------------------------------------------------------------------------------
+    // The wave's 64 bias values travel through its LDS scratch: one 4-byte-per-lane DMA at the START of the tile (the
+    // scratch is idle during the K loop; columns beyond N read as zero through the descriptor's bounds check), so the
+    // epilogue starts with LDS reads instead of a global-memory round trip.
+    char* scr = smem + SCRATCH0 + wave * SCRATCH_WAVE;
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * 4u : 0u, 0x00020000);
+    auto bias_prefetch = [&](int nw) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)scr, 4,
+                                                 (unsigned)(nw + lane_now()) * 4u, 0, 0, 0);
+    };
+    auto act_apply = [&](auto ac, float v) __attribute__((always_inline)) -> float {
+        constexpr int ACT = decltype(ac)::v;
+        if constexpr (ACT == MOFA_ACT_SILU) return silu_f(v);
+        else if constexpr (ACT == MOFA_ACT_RELU) return fmaxf(v, 0.0f);
+        else if constexpr (ACT == MOFA_ACT_GELU) return gelu_erf_f(v);
+        else return v;
+    };
+    // kinds without residuals (plain, row vector, GEGLU): bias / row vector / activation in the accumulator (fragment)
+    // layout -- register r of accumulator tile (i, j) is row 32 i + l31, column 32 j + 8 (r >> 2) + 4 lh + (r & 3) --
+    // then fp16 and a 32 x 64 fp16 transpose through the scratch; a lane stores 8 consecutive columns of one row
+    auto epilogue_light = [&](auto ac, f32x16 (&acc)[MI][NJ], const int mw, const int nw) __attribute__((always_inline)) {
+        f16* out = (f16*)a.out;
+        float saccv = a.s_acc;                                     // VGPR operand on purpose (see igemm.hip's epilogue)
+        asm volatile("" : "+v"(saccv));
+        f32x4 bv[NJ][4];
+        if (!RV) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[j][g] = *(const f32x4*)(scr + (32 * j + 8 * g + 4 * lh) * 4);
+        }
+        const int nout = GEGLU ? a.N / 2 : a.N;
+        int rv_div = a.rv_div, rv_mod_in = a.rv_mod_in, rv_mod_out = a.rv_mod_out;
+        asm volatile("" : "+s"(rv_div), "+s"(rv_mod_in), "+s"(rv_mod_out));   // reciprocals are set up here, not hoisted
+        // row-vector values of accumulator row block i: block i + 1's are loaded as soon as block i's arithmetic is
+        // done (same registers), so the load latency hides behind block i's transpose and stores
+        f32x4 rv[NJ][4];
+        auto rv_load = [&](int i, f32x4 (&rv)[NJ][4]) __attribute__((always_inline)) {
+            int m = mw + 32 * i + l31;
+            m = m < a.M ? m : a.M - 1;
+            const int idx = ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
+            const float* rvp = a.rowvec + (size_t)idx * a.N;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int n = nw + 32 * j + 8 * g + 4 * lh;
+                    n = n + 4 <= a.N ? n : 0;                       // columns beyond N are never stored
+                    rv[j][g] = *(const f32x4*)(rvp + n);
+                    if (a.bias) rv[j][g] += *(const f32x4*)(a.bias + n);   // (row-vector kinds: bias rides along, L1-hot)
+                }
+        };
+        if (RV) rv_load(0, rv);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            if constexpr (GEGLU) {
+                // value tile j = 0, gate tile j = 1 (weight rows interleaved in blocks of 32 at load time); the outputs
+                // of accumulator rows i (even) and i + 1 share one scratch image: columns 0..31 / 32..63
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] = (f16)(saccv * (acc[i][0][4 * g + e] + bv[0][g][e]) *
+                                     gelu_erf_f(saccv * (acc[i][1][4 * g + e] + bv[1][g][e])));
+                    *(f16x4*)(scr + h16_off(l31, 8 * (i & 1) + 2 * g + lh)) = o;
+                }
+                if (i & 1) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const int row = 8 * p + (lane >> 3), blk = lane & 7;
+                        const f16x8 v = *(const f16x8*)(scr + row * 128 + ((blk ^ ((row >> 1) & 7)) << 4));
+                        const int m = mw + 32 * (i - 1 + (blk >> 2)) + row;
+                        const int n = nw / 2 + 8 * (blk & 3);
+                        f16x8 o = v;
+                        if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                        if (m < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float v = acc[i][j][4 * g + e] + (RV ? rv[j][g][e] : bv[j][g][e]);
+                            o[e] = (f16)act_apply(ac, saccv * v);
+                        }
+                        *(f16x4*)(scr + h16_off(l31, 8 * j + 2 * g + lh)) = o;
+                    }
+                if (RV && i + 1 < MI) rv_load(i + 1, rv);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = 8 * p + (lane >> 3), blk = lane & 7;
+                    const f16x8 v = *(const f16x8*)(scr + row * 128 + ((blk ^ ((row >> 1) & 7)) << 4));
+                    const int m = mw + 32 * i + row, n = nw + 8 * blk;
+                    f16x8 o = v;
+                    if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                    if (m < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
+                }
+            }
+        }
+    };
+    // kinds with residuals: fp32 transpose, 32 x 32 per step (8 steps: accumulator tiles (i, j)); a lane owns 8 consecutive
+    // columns of one row.  The residual / row-vector loads of step s + D are issued before step s is processed (a ring of
+    // D steps in registers; D from the registers a step's loads take), so their latency hides behind D steps of work.
+    auto epilogue_residual = [&](f32x16 (&acc)[MI][NJ], const int mw, const int nw) __attribute__((always_inline)) {
+        constexpr int STEPS = MI * NJ;
+        constexpr int REGS = (R1 ? 8 : 0) + (R2 ? 8 : 0) + (RV ? 16 : 0);     // VGPRs of one step's loads
+        constexpr int D = REGS <= 8 ? 8 : (REGS <= 16 ? 4 : (REGS <= 24 ? 2 : 1));
+        f16* out = (f16*)a.out;
+        const f16* r1 = (const f16*)a.r1;
+        const f16* r2 = (const f16*)a.r2;
+        float s1v = a.s1, s2v = a.s2, saccv = a.s_acc;
+        asm volatile("" : "+v"(s1v), "+v"(s2v), "+v"(saccv));
+        int rv_div = a.rv_div, rv_mod_in = a.rv_mod_in, rv_mod_out = a.rv_mod_out;
+        asm volatile("" : "+s"(rv_div), "+s"(rv_mod_in), "+s"(rv_mod_out));
+        const int piece = lane & 3;
+        struct StepLoads { f16x8 t1[2], t2[2]; f32x4 rv0[2], rv1[2]; };
+        StepLoads L[D];
+        auto step_loads = [&](int st, StepLoads& l) __attribute__((always_inline)) {
+            const int i = st / NJ, j = st % NJ;
+            const int n = nw + 32 * j + 8 * piece;
+            const int nc = n + 8 <= a.N ? n : 0;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                int m = mw + 32 * i + 16 * p + (lane >> 2);
+                m = m < a.M ? m : a.M - 1;
+                if (R1) l.t1[p] = *(const f16x8*)(r1 + (size_t)m * a.ldr1 + nc);
+                if (R2) l.t2[p] = *(const f16x8*)(r2 + (size_t)m * a.ldr2 + nc);
+                if (RV) {
+                    const int idx = ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
+                    const float* q = a.rowvec + (size_t)idx * a.N + nc;
+                    l.rv0[p] = *(const f32x4*)q;
+                    l.rv1[p] = *(const f32x4*)(q + 4);
+                }
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < D && st < STEPS; ++st) step_loads(st, L[st]);
+        f32x4 bv[NJ][2];                                           // bias of this lane's 8 columns, from the scratch
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            bv[j][0] = *(const f32x4*)(scr + (32 * j + 8 * piece) * 4);
+            bv[j][1] = *(const f32x4*)(scr + (32 * j + 8 * piece + 4) * 4);
+        }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int i = st / NJ, j = st % NJ;
+            StepLoads& l = L[st % D];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                *(f32x4*)(scr + f32_off(l31, 2 * g + lh)) = v;
+            }
+            const int n = nw + 32 * j + 8 * piece;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int row = 16 * p + (lane >> 2);
+                const f32x4 v0 = *(const f32x4*)(scr + f32_off(row, 2 * piece));
+                const f32x4 v1 = *(const f32x4*)(scr + f32_off(row, 2 * piece + 1));
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = v0[e] + bv[j][0][e], x1 = v1[e] + bv[j][1][e];
+                    if (RV) { x0 += l.rv0[p][e]; x1 += l.rv1[p][e]; }
+                    x0 *= saccv; x1 *= saccv;
+                    if (R1) { x0 += s1v * (float)l.t1[p][e]; x1 += s1v * (float)l.t1[p][4 + e]; }
+                    if (R2) { x0 += s2v * (float)l.t2[p][e]; x1 += s2v * (float)l.t2[p][4 + e]; }
+                    o[e] = (f16)x0; o[4 + e] = (f16)x1;
+                }
+                const int m = mw + 32 * i + row;
+                if (m < a.M && n + 8 <= a.N) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
+            }
+            if (st + D < STEPS) step_loads(st + D, L[st % D]);     // refill the ring slot just consumed
+        }
+    };
 
     int gt = 0;                                                    // K tiles consumed so far (ring slot = gt & 1)
     for (int cl = walk.local; cl < walk.count; cl += walk.stride) {
         const int tile = walk.start + cl;
         const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
-        f32x16 acc[MI][NJ];
+        if (VAR & 64) { stamp(9); tr[12] += nk; }          // tile set-up since the last stamp
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -220,282 +494,75 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-        if (grp == 1) __builtin_amdgcn_s_barrier();                // second wave group runs one barrier behind
+        bias_prefetch(tn * TBN + wn * NJ * 32);                    // (no bias: an empty descriptor, zeros arrive)
+        if (!(VAR & 1) && grp == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
         for (int kt = 0; kt < nk; ++kt, ++gt) {
             const int bo = (gt & 1) * STB, bn = STB - bo;          // ring slot of this K tile / of the next one
-            const char* sb = smem + bo;
-            f16x8 xf[2][4], w0[4], w1[4];
-            // ---------------- phase 1: X0 x W0 ----------------
+            phase(IC<1>{}, bo, bn);
+            phase(IC<2>{}, bo, bn);
 #pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) xf[il][kk] = *(const f16x8*)(sb + xfrag + il * 32 * RB + slot[kk]);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) w0[kk] = *(const f16x8*)(sb + wfrag + slot[kk]);
-            issue_w(cb, 1, bn);
-            wait_vmcnt_only<LOOKAHEAD_OPS>();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int il = 0; il < 2; ++il)
-                    acc[il][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kk], xf[il][kk], acc[il][0], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- phase 2: X0 x W1 ----------------
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) w1[kk] = *(const f16x8*)(sb + wfrag + 32 * RB + slot[kk]);
-            issue_x(cb, 1, bn);
-            advance(cb, 1);
-            wait_vmcnt_only<LOOKAHEAD_OPS>();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int il = 0; il < 2; ++il)
-                    acc[il][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kk], xf[il][kk], acc[il][1], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- phase 3: X1 x W1 ----------------
-#pragma unroll
-            for (int il = 0; il < 2; ++il)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) xf[il][kk] = *(const f16x8*)(sb + xfrag + (2 + il) * 32 * RB + slot[kk]);
-            issue_x(ca, 0, bo);
-            wait_vmcnt_only<LOOKAHEAD_OPS>();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int il = 0; il < 2; ++il)
-                    acc[2 + il][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1[kk], xf[il][kk], acc[2 + il][1], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            // ---------------- phase 4: X1 x W0 ----------------
-            issue_w(ca, 0, bo);
-            advance(ca, 0);
-            wait_vmcnt_only<LOOKAHEAD_OPS>();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int il = 0; il < 2; ++il)
-                    acc[2 + il][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0[kk], xf[il][kk], acc[2 + il][0], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            for (int kk = 0; kk < 4; ++kk) { xa[kk] ^= STB; wa[kk] ^= STB; }   // the next K tile's ring slot
         }
-        if (grp == 0) __builtin_amdgcn_s_barrier();                // both groups meet again: equal barrier counts per tile
+        if (!(VAR & 1) && grp == 0) __builtin_amdgcn_s_barrier();  // both groups meet again: equal barrier counts per tile
+        stamp(6);                                                  // (re-sync barrier of the first wave group)
 
         // ---- epilogue (no barriers; private scratch) ------------------------------------------------------------------
-        char* scr = smem + SCRATCH0 + wave * SCRATCH_WAVE;
         const int mw = tm * TBM + wm * MI * 32;                    // first output row / (pre-GEGLU) column of this wave
         const int nw = tn * TBN + wn * NJ * 32;
-        f16* out = (f16*)a.out;
-        float s1v = a.s1, s2v = a.s2, saccv = a.s_acc;             // VGPR operands on purpose (see igemm.hip's epilogue)
-        asm volatile("" : "+v"(s1v), "+v"(s2v), "+v"(saccv));
-        int rv_div = a.rv_div, rv_mod_in = a.rv_mod_in, rv_mod_out = a.rv_mod_out;
-        asm volatile("" : "+s"(rv_div), "+s"(rv_mod_in), "+s"(rv_mod_out));   // reciprocals are set up here, not hoisted
-        if constexpr (!R1 && !R2) {
-            // ---- fragment-layout math, fp16 transpose.  register r of accumulator tile (i, j): row 32 i + l31, column
-            //      32 j + 8 (r >> 2) + 4 lh + (r & 3)
-            f32x4 bv[NJ][4];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    int n = nw + 32 * j + 8 * g + 4 * lh;
-                    n = n + 4 <= a.N ? n : 0;                       // columns beyond N are never stored
-                    bv[j][g] = a.bias ? *(const f32x4*)(a.bias + n) : (f32x4){0, 0, 0, 0};
-                }
-            const int nout = GEGLU ? a.N / 2 : a.N;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const float* rvp = nullptr;
-                if (RV) {
-                    int m = mw + 32 * i + l31;
-                    m = m < a.M ? m : a.M - 1;
-                    const int idx = ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
-                    rvp = a.rowvec + (size_t)idx * a.N;
-                }
-                if constexpr (GEGLU) {
-                    // value tile j = 0, gate tile j = 1 (weight rows interleaved in blocks of 32 at load time); the
-                    // outputs of accumulator rows i (even) and i + 1 share one scratch image: columns 0..31 / 32..63
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f16x4 o;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            o[e] = (f16)(saccv * (acc[i][0][4 * g + e] + bv[0][g][e]) *
-                                         gelu_erf_f(saccv * (acc[i][1][4 * g + e] + bv[1][g][e])));
-                        *(f16x4*)(scr + h16_off(l31, 8 * (i & 1) + 2 * g + lh)) = o;
-                    }
-                    if (i & 1) {
-#pragma unroll
-                        for (int p = 0; p < 4; ++p) {
-                            const int row = 8 * p + (lane >> 3), blk = lane & 7;
-                            const f16x8 v = *(const f16x8*)(scr + row * 128 + ((blk ^ ((row >> 1) & 7)) << 4));
-                            const int m = mw + 32 * (i - 1 + (blk >> 2)) + row;
-                            const int n = nw / 2 + 8 * (blk & 3);
-                            f16x8 o = v;
-                            if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-                            if (m < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 rv = {0, 0, 0, 0};
-                            if (RV) {
-                                int n = nw + 32 * j + 8 * g + 4 * lh;
-                                n = n + 4 <= a.N ? n : 0;
-                                rv = *(const f32x4*)(rvp + n);
-                            }
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = saccv * (acc[i][j][4 * g + e] + bv[j][g][e] + rv[e]);
-                            if (a.act == MOFA_ACT_SILU) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-                            } else if (a.act == MOFA_ACT_RELU) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-                            } else if (a.act == MOFA_ACT_GELU) {
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
-                            }
-                            const f16x4 o = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-                            *(f16x4*)(scr + h16_off(l31, 8 * j + 2 * g + lh)) = o;
-                        }
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const int row = 8 * p + (lane >> 3), blk = lane & 7;
-                        const f16x8 v = *(const f16x8*)(scr + row * 128 + ((blk ^ ((row >> 1) & 7)) << 4));
-                        const int m = mw + 32 * i + row, n = nw + 8 * blk;
-                        f16x8 o = v;
-                        if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-                        if (m < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
-                    }
-                }
-            }
-        } else {
-            // ---- residual kinds: fp32 transpose, 32 x 32 per pass; a lane owns 8 consecutive columns of one row ----
-            const int piece = lane & 3;
-            const f16* r1 = (const f16*)a.r1;
-            const f16* r2 = (const f16*)a.r2;
-            f32x4 bv[NJ][2];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                int n = nw + 32 * j + 8 * piece;
-                n = n + 8 <= a.N ? n : 0;
-                bv[j][0] = a.bias ? *(const f32x4*)(a.bias + n) : (f32x4){0, 0, 0, 0};
-                bv[j][1] = a.bias ? *(const f32x4*)(a.bias + n + 4) : (f32x4){0, 0, 0, 0};
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int n = nw + 32 * j + 8 * piece;
-                    const int nc = n + 8 <= a.N ? n : 0;
-                    // residual / row-vector loads of both passes go out before the transpose
-                    f16x8 t1[2], t2[2];
-                    f32x4 rv0[2], rv1[2];
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        int m = mw + 32 * i + 16 * p + (lane >> 2);
-                        m = m < a.M ? m : a.M - 1;
-                        if (R1) t1[p] = *(const f16x8*)(r1 + (size_t)m * a.ldr1 + nc);
-                        if (R2) t2[p] = *(const f16x8*)(r2 + (size_t)m * a.ldr2 + nc);
-                        if (RV) {
-                            const int idx = ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
-                            const float* q = a.rowvec + (size_t)idx * a.N + nc;
-                            rv0[p] = *(const f32x4*)q;
-                            rv1[p] = *(const f32x4*)(q + 4);
-                        }
-                    }
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                        *(f32x4*)(scr + f32_off(l31, 2 * g + lh)) = v;
-                    }
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const int row = 16 * p + (lane >> 2);
-                        const f32x4 v0 = *(const f32x4*)(scr + f32_off(row, 2 * piece));
-                        const f32x4 v1 = *(const f32x4*)(scr + f32_off(row, 2 * piece + 1));
-                        float v[8];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float x0 = v0[e] + bv[j][0][e], x1 = v1[e] + bv[j][1][e];
-                            if (RV) { x0 += rv0[p][e]; x1 += rv1[p][e]; }
-                            x0 *= saccv; x1 *= saccv;
-                            if (R1) { x0 += s1v * (float)t1[p][e]; x1 += s1v * (float)t1[p][4 + e]; }
-                            if (R2) { x0 += s2v * (float)t2[p][e]; x1 += s2v * (float)t2[p][4 + e]; }
-                            v[e] = x0; v[4 + e] = x1;
-                        }
-                        if (a.act == MOFA_ACT_SILU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-                        } else if (a.act == MOFA_ACT_RELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.0f);
-                        } else if (a.act == MOFA_ACT_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_erf_f(v[e]);
-                        }
-                        const int m = mw + 32 * i + row;
-                        if (m < a.M && n + 8 <= a.N) {
-                            f16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) o[e] = (f16)v[e];
-                            *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
-                        }
-                    }
-                }
+        if constexpr (R1 || R2) {
+            epilogue_residual(acc, mw, nw);
+        } else if constexpr (GEGLU) {
+            epilogue_light(IC<MOFA_ACT_NONE>{}, acc, mw, nw);
+        } else {                                                   // uniform dispatch: the activation is compiled in
+            if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, acc, mw, nw);
+            else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, acc, mw, nw);
+            else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, acc, mw, nw);
+            else epilogue_light(IC<MOFA_ACT_GELU>{}, acc, mw, nw);
         }
+        if (VAR & 64) { stamp(7); tr[8] += 1; }                   // epilogue (stores still in flight); tiles
     }
     // a wave must not retire with an LDS DMA in flight (the cursors' run-ahead past the last tile)
     wait_vmcnt_only<0>();
+    if ((VAR & 64) && aux.trace && (tid & 255) == 0) {
+#pragma unroll
+        for (int k = 0; k < 13; ++k) aux.trace[((size_t)blockIdx.x * 2 + grp) * 16 + k] = tr[k];
+    }
 }
+
+typedef void (*igemm8_kern_t)(const mofa_igemm_args, const int, const int, const Aux);
 
 }  // namespace
 
-typedef void (*igemm8_kern_t)(const mofa_igemm_args, const int, const int, const Aux);
 static const igemm8_kern_t k_igemm8[9] = {igemm8_f16_kernel<0>, igemm8_f16_kernel<1>, igemm8_f16_kernel<2>,
                                            igemm8_f16_kernel<3>, igemm8_f16_kernel<4>, igemm8_f16_kernel<5>,
                                            igemm8_f16_kernel<6>, igemm8_f16_kernel<7>, igemm8_f16_kernel<8>};
 
-static const f16* s_zero_page = nullptr;
+
+// diagnostic hook of tools/igemm8_probe.py (not part of the C ABI in mofa_hip.h): plain-epilogue launches run K-loop build
+// variant `var` (see the kernel's VAR) and, for var & 64, write per-segment cycle sums to `trace` ([grid][2][16] u64)
+static int s_probe_var = 0;
+static unsigned long long* s_probe_trace = nullptr;
+static const int k_probe_vars[] = {1, 2, 4, 8, 16, 32, 48, 64};
+static const igemm8_kern_t k_trace_kern[9] = {nullptr, igemm8_f16_kernel<1, 64>, nullptr, nullptr, igemm8_f16_kernel<4, 64>, nullptr, nullptr,
+                                               nullptr, igemm8_f16_kernel<8, 64>};
+static const igemm8_kern_t k_probe_kern[] = {
+    igemm8_f16_kernel<0, 1>, igemm8_f16_kernel<0, 2>, igemm8_f16_kernel<0, 4>, igemm8_f16_kernel<0, 8>,
+    igemm8_f16_kernel<0, 16>, igemm8_f16_kernel<0, 32>, igemm8_f16_kernel<0, 48>, igemm8_f16_kernel<0, 64>};
+extern "C" int mofa_igemm8_set_probe(int var, void* trace) {
+    s_probe_var = var;
+    s_probe_trace = (unsigned long long*)trace;
+    return 0;
+}
 
 int igemm8_init() {
-    void* zp = nullptr;
-    if (hipGetSymbolAddress(&zp, HIP_SYMBOL(g_zero_page)) != hipSuccess || !zp) return MOFA_ELAUNCH;
-    s_zero_page = (const f16*)zp;
     for (igemm8_kern_t k : k_igemm8)
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return MOFA_ELAUNCH;
+    for (igemm8_kern_t k : k_probe_kern)
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return MOFA_ELAUNCH;
+    for (igemm8_kern_t k : k_trace_kern)
+        if (k && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
     return MOFA_OK;
 }
@@ -513,6 +580,13 @@ static FastDiv fastdiv_make(int d) {
     return f;
 }
 
+// rows of the activation buffer the launch may address (convT3 without clipping: one halo frame on either side)
+static long long igemm8_rows_in(const mofa_igemm_args* a) {
+    if (a->mode == MOFA_MODE_CONV3X3) return a->M / ((long long)a->Hout * a->Wout) * a->Hin * a->Win;
+    if (a->mode == MOFA_MODE_CONVT3 && a->T == 0) return (long long)a->M + 2ll * a->HW;
+    return a->M;
+}
+
 // 16-byte row alignment everywhere (the kernel has no narrow-store path); packed row geometry and 32-bit offsets in range
 static bool igemm8_eligible(const mofa_igemm_args* a, int kind, long long Ktot) {
     const int nout = kind == 8 ? a->N / 2 : a->N;
@@ -520,18 +594,16 @@ static bool igemm8_eligible(const mofa_igemm_args* a, int kind, long long Ktot) 
     if (a->r1 && ((a->ldr1 & 7) || (((size_t)a->r1) & 15))) return false;
     if (a->r2 && ((a->ldr2 & 7) || (((size_t)a->r2) & 15))) return false;
     if (a->bias && (((size_t)a->bias) & 15)) return false;
+    if ((a->r1 || a->r2) && a->act != MOFA_ACT_NONE) return false;        // residual kinds carry no activation code here
     if (a->rowvec && (((size_t)a->rowvec) & 15)) return false;
     if ((long long)a->N * Ktot * 2 >= (1ll << 32) || (((size_t)a->w) & 15)) return false;
-    long long rows_in = a->M;
     if (a->mode == MOFA_MODE_CONV3X3) {
         const long long nimg = a->M / ((long long)a->Hout * a->Wout);
         if (a->Hout > 1024 || a->Wout > 1024 || nimg > 2047) return false;
-        rows_in = nimg * a->Hin * a->Win;
     } else if (a->mode == MOFA_MODE_CONVT3) {
         if (a->M >= (1 << 29)) return false;
-        rows_in = (long long)a->M + a->HW;
     }
-    if (rows_in * (a->ldx / 8) >= (1ll << 31)) return false;
+    if (igemm8_rows_in(a) * a->ldx * 2 >= (1ll << 32) - 65536) return false;   // 32-bit buffer offsets
     return true;
 }
 
@@ -547,11 +619,21 @@ int igemm8_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stre
     aux.wout = fastdiv_make(a->mode == MOFA_MODE_CONV3X3 ? a->Wout : 1);
     aux.t3hw = fastdiv_make(a->mode == MOFA_MODE_CONVT3 ? a->HW : 1);
     aux.t3t = fastdiv_make(a->mode == MOFA_MODE_CONVT3 && a->T > 0 ? a->T : 1);
-    aux.ldx16 = a->ldx / 8;
-    aux.zero = s_zero_page;
+    const bool halo = a->mode == MOFA_MODE_CONVT3 && a->T == 0;   // rows before a.x are read (tap -1 of the first frame)
+    aux.ldxb = a->ldx * 2;
+    aux.row_shift = halo ? a->HW : 0;
+    aux.xbase = (const char*)a->x - (halo ? (size_t)a->HW * a->ldx * 2 : 0);
+    aux.x_bytes = (unsigned)(igemm8_rows_in(a) * a->ldx * 2 - (a->ldx - a->Cin) * 2);
+    aux.w_bytes = (unsigned)((long long)a->N * taps * a->Cin * 2);
+    aux.trace = s_probe_trace;
+    igemm8_kern_t kern = k_igemm8[kind];
+    if (kind == 0 && s_probe_var)
+        for (size_t i = 0; i < sizeof(k_probe_vars) / sizeof(int); ++i)
+            if (k_probe_vars[i] == s_probe_var) kern = k_probe_kern[i];
+    if (s_probe_var == 64 && k_trace_kern[kind]) kern = k_trace_kern[kind];
     int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL(k_igemm8[kind], dim3(grid), dim3(512), LDS_BYTES, stream, *a, tilesN, (int)nt, aux);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, stream, *a, tilesN, (int)nt, aux);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mofa_video_amd import lib, ops  # noqa: E402
 
 DEV = "cuda"
-TILES = [("128", lib.TILE_128X128), ("192", lib.TILE_192X128), ("256s2", lib.TILE_256X256_2STAGE), ("256p", lib.TILE_256X256),
+TILES = [("128", lib.TILE_128X128), ("192", lib.TILE_192X128), ("256p", lib.TILE_256X256),
          ("auto", lib.TILE_AUTO)]
 
 # (mode, M-or-(n,H,W), N, Cin, epilogue, launches per denoise step [UNet + ControlNet], tag)
@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--quick", action="store_true", help="first 10 shapes only")
-    ap.add_argument("--tiles", default="128,192,256s2,256p,auto")
+    ap.add_argument("--tiles", default="128,192,256p,auto")
     args = ap.parse_args()
     lib.load()
     tiles = [t for t in TILES if t[0] in args.tiles.split(",")]
