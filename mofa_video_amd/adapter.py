@@ -86,6 +86,30 @@ class FlowControlNet:
     def from_module(cls, module, device="cuda"):
         return cls(module.state_dict(), getattr(module, "config", None), device)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", variant=None, **unused):
+        """checkpoint directory of the trained adapter (MOFA-Video-Traj/run_gradio.py:106-110).  As in the reference, the
+        trunk architecture does NOT come from ``config.json``: ``FlowControlNet.__init__`` calls ``super().__init__()``
+        without arguments (svdxt_..._norefine.py:213), so it is always ControlNetSDVModel's default (heads (5, 10, 10, 20))"""
+        from . import checkpoint
+        path = checkpoint.resolve_dir(pretrained_model_name_or_path, subfolder)
+        checkpoint.load_config(path)                                  # must exist, as for diffusers' loader
+        return cls(checkpoint.load_state_dict(path, variant), None, device)
+
+    @classmethod
+    def _schema(cls, config=None):
+        from . import schema
+        return schema.controlnet_schema(config)
+
+    @classmethod
+    def from_unet(cls, unet, load_weights_from_unet=True, device="cuda", seed=0, config=None, **unused):
+        """``ControlNetSDVModel.from_unet`` (MOFA-Video-Traj/models/controlnet_sdv.py:572-628): a fresh adapter whose
+        ``conv_in`` / ``time_embedding`` / ``down_blocks`` / ``mid_block`` are copies of the UNet's, zero-initialised output
+        convolutions, default-initialised everything else.  ``unet``: a state_dict, or anything with ``state_dict()``"""
+        from . import checkpoint
+        sd = unet if isinstance(unet, dict) else unet.state_dict()
+        return cls(checkpoint.controlnet_state_dict_from_unet(sd, cls._schema(config), load_weights_from_unet, seed), config, device)
+
     # -- timestep-invariant adapter work (svdxt_...norefine.py:297-319) -------------------------------------
     def prepare_condition(self, controlnet_cond, controlnet_flow, frames=None):
         """controlnet_cond [1,3,H,W]; controlnet_flow [1,T-1,2,H,W] -> list of 4 token-major fp16 tensors
@@ -265,6 +289,11 @@ class _Matting:
 
 
 class LandmarkFlowControlNet(FlowControlNet):
+    @classmethod
+    def _schema(cls, config=None):
+        from . import schema
+        return schema.ldmk_controlnet_schema(config)
+
     """``FlowControlNet`` of MOFA-Video-Hybrid/models/ldmk_ctrlnet.py (= MOFA-Video-Keypoint/models/ldmk_ctrlnet.py):
     the trajectory adapter (first-frame encoder without zero convs) + landmark-image embedding added at the 320-channel
     stages + per-scale ForegroundMatting and zero-out on every warped frame.  ``forward`` adds the ``landmarks``

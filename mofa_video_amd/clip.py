@@ -119,6 +119,17 @@ class CLIPVisionModelWithProjection:
         get = (lambda k: cfg[k]) if isinstance(cfg, dict) else (lambda k: getattr(cfg, k))
         return cls(module.state_dict(), {k: get(k) for k in keys}, device)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", variant=None, **unused):
+        """``image_encoder/`` of the SVD-XT checkpoint directory (transformers layout: ``config.json`` + ``model.safetensors``)"""
+        from . import checkpoint
+        path = checkpoint.resolve_dir(pretrained_model_name_or_path, subfolder)
+        raw = checkpoint.load_config(path)
+        raw = dict(raw.get("vision_config") or {}, **{k: v for k, v in raw.items() if k != "vision_config"})
+        keys = ("hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads", "image_size", "patch_size",
+                "projection_dim", "layer_norm_eps")
+        return cls(checkpoint.load_state_dict(path, variant), {k: raw[k] for k in keys if k in raw}, device)
+
     def parameters(self):                                                                    # dtype probe of pipeline.py:115
         yield self.wpatch
 

@@ -40,9 +40,11 @@ def _resize_with_antialiasing(input, size, interpolation="bicubic", align_corner
 
 
 def image_to_01(image, height, width, device):
-    """PIL image(s) / numpy / tensor -> fp32 [1, 3, height, width] in [0, 1] on ``device`` (VaeImageProcessor
-    pil_to_numpy + numpy_to_pt, pipeline.py:118-119).  PIL inputs of another size are resized on the host with PIL's
-    lanczos filter, as VaeImageProcessor.resize does; tensors must already be height x width."""
+    """PIL image(s) / numpy / tensor -> fp32 [1, 3, h, w] in [0, 1] on ``device`` (VaeImageProcessor pil_to_numpy +
+    numpy_to_pt, pipeline.py:118-119).  ``height`` / ``width`` None: the image keeps its own size (what the reference's
+    ``_encode_image`` feeds to the 224 x 224 antialiased resize).  Otherwise the size ``image_processor.preprocess(image,
+    height, width)`` produces (:338, :391): PIL inputs are resized on the host with PIL's lanczos filter, numpy / tensor
+    inputs by nearest-neighbour interpolation (``F.interpolate`` default), as VaeImageProcessor.resize does."""
     if isinstance(image, (list, tuple)):
         if len(image) != 1:
             raise ValueError("one clip per call: pass a single conditioning image")
@@ -53,7 +55,7 @@ def image_to_01(image, height, width, device):
             t = t.unsqueeze(0)
     else:
         if hasattr(image, "resize") and hasattr(image, "size") and not isinstance(image, np.ndarray):
-            if tuple(image.size) != (width, height):
+            if height is not None and tuple(image.size) != (width, height):
                 from PIL import Image
                 image = image.resize((width, height), resample=Image.LANCZOS)
             image = np.array(image.convert("RGB")).astype(np.float32) / 255.0
@@ -61,9 +63,25 @@ def image_to_01(image, height, width, device):
         if t.dim() == 3:
             t = t.unsqueeze(0)
         t = t.permute(0, 3, 1, 2)
-    if t.shape[0] != 1 or t.shape[1] != 3 or tuple(t.shape[-2:]) != (height, width):
-        raise ValueError(f"conditioning image is {tuple(t.shape)}, expected (1, 3, {height}, {width})")
-    return t.to(device).contiguous()
+    if t.shape[0] != 1 or t.shape[1] != 3:
+        raise ValueError(f"conditioning image is {tuple(t.shape)}, expected (1, 3, H, W)")
+    t = t.to(device).contiguous()
+    if height is not None and tuple(t.shape[-2:]) != (height, width):
+        t = ops.resize_nearest_f32(t[0], height, width).unsqueeze(0)
+    return t.contiguous()
+
+
+def preprocess(image, height, width, device):
+    """``VaeImageProcessor.preprocess(image, height, width)`` (diffusers 0.24.0 image_processor.py, called at pipeline.py:338
+    and :391): resize as in ``image_to_01``, then ``normalize`` to [-1, 1] -- unless a tensor input already holds negative
+    values, in which case diffusers warns and skips the normalisation.  fp32 [1, 3, height, width]."""
+    already = torch.is_tensor(image) and bool((image.min() < 0).item())
+    x = image_to_01(image, height, width, device)
+    if already:
+        return x
+    y = x.clone()
+    ops.axpby_f32_(torch.ones_like(x), y, a=-1.0, b=2.0)               # 2 x - 1
+    return y
 
 
 @torch.no_grad()

@@ -1,6 +1,8 @@
-"""MI355X host mirror of ``FlowControlNetPipeline`` (MOFA-Video-Traj/pipeline/pipeline.py:87-527).
+"""MI355X host mirrors of the reference pipelines: ``FlowControlNetPipeline`` (MOFA-Video-Traj/pipeline/pipeline.py:87-527),
+``HybridFlowControlNetPipeline`` (MOFA-Video-Hybrid/pipeline/pipeline.py:293-507) and ``KeypointFlowControlNetPipeline``
+(MOFA-Video-Keypoint/pipeline/svdxt_pipeline_ctrlnet_loop.py:289-511).
 
-Same constructor modules and ``__call__`` signature / defaults / return type.  The denoise loop runs
+Same constructor modules, ``__call__`` signatures, defaults (``output_type="pil"``) and return types.  The denoise loops run
 entirely in libmofa_hip.so on token-major fp16 activations:
 
     per clip (hoisted, timestep-invariant -- SURVEY F7/F11):
@@ -8,7 +10,7 @@ entirely in libmofa_hip.so on token-major fp16 activations:
         cross-attention row vectors and frame-position embeddings of every transformer layer
     per step:
         mofa_prepare_model_input   (scale by 1/sqrt(sigma^2+1), concat image latents, both CFG halves)
-        FlowControlNet.forward_tokens -> 12 + 1 residuals
+        FlowControlNet.forward_tokens -> 12 + 1 residuals   (Hybrid: two adapters + mask blend)
         UNet.forward_tokens           -> noise prediction
         mofa_cfg_euler_step         (CFG with per-frame guidance + v-prediction Euler step, fp32 latents)
     decode: temporal VAE decoder, chunks of ``decode_chunk_size`` frames.
@@ -18,8 +20,13 @@ pipeline holds an ``image_encoder`` (mofa_video_amd.clip) and a VAE with encoder
 [1,3,H,W] tensor in [0, 1] of the reference call (mofa_video_amd/frontend.py).  Precomputed conditioning can be passed
 instead through the keyword-only extensions ``image_embeddings`` ([1,1,1024] or [2,1,1024]) and ``image_latents``
 ([1,4,h,w] or [2,4,h,w]).
+
 Reference quirks kept: ``added_time_ids`` is always [6, 128, 0.02] (pipeline.py:430-440); CFG is always on
-(max_guidance_scale > 1); the scheduler's unused per-step randn draw is not reproduced (no effect on results).
+(max_guidance_scale > 1).  Stated deviations: (1) the latents stay fp32 between steps unless the pipeline is built with
+``round_latents_to_fp16=True`` (the reference's fp16 run rounds them every step, scheduling_..._karras_fix.py:520);
+(2) random draws (initial latents, noise augmentation) come from ``torch.randn`` in fp32 on the generator's device, so a
+seed does not reproduce the reference's fp16 CUDA draws -- pass ``latents=`` for reproducibility across implementations;
+(3) the scheduler's unused per-step randn draw is not made (no effect on results).
 """
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Union
@@ -39,36 +46,83 @@ class FlowControlNetPipelineOutput:
     controlnet_flow: Union[List, np.ndarray, torch.FloatTensor]
 
 
-def _to_tensor_image(image, height, width, device):
-    """controlnet_condition: VaeImageProcessor.preprocess for tensors is a resize + (2x-1); here only tensors in [-1,1]
-    that are already H x W are accepted (the conditioning *image* goes through frontend.image_to_01 instead)."""
-    if not torch.is_tensor(image):
-        raise ValueError("mofa_video_amd pipeline expects a torch tensor [1,3,H,W] in [-1,1] for image / "
-                         f"controlnet_condition, got {type(image)}")
-    if image.dim() == 3:
-        image = image.unsqueeze(0)
-    if tuple(image.shape[-2:]) != (height, width):
-        raise ValueError(f"image is {tuple(image.shape[-2:])}, expected ({height}, {width})")
-    return image.to(device, torch.float32)
+MAX_TEMPORAL_FRAMES = 32        # mofa_attn_temporal_f16 holds one clip's keys in a wave: T <= 32
+
+
+class _Shard:
+    """what this rank computes of a T-frame clip (mofa_video_amd/parallel.py): frames [f0, f1), Bl CFG halves"""
+
+    def __init__(self, par, T):
+        self.par = par
+        self.lay = par.lay if par is not None else None
+        if self.lay is not None and self.lay.T != T:
+            raise ValueError(f"the parallel Layout was built for {self.lay.T} frames, the clip has {T}")
+        self.f0, self.f1 = (self.lay.f0, self.lay.f1) if self.lay is not None else (0, T)
+        self.Tl = self.f1 - self.f0
+        self.Bl = self.lay.B_loc if self.lay is not None else 2
+        self.half = self.lay.half if self.lay is not None else None
+        self.fpar = par if (self.lay is not None and self.lay.sharded_frames) else None
+        self.world = self.lay.world if self.lay is not None else 1
+        self.rank = self.lay.rank if self.lay is not None else 0
 
 
 class FlowControlNetPipeline:
     def __init__(self, vae=None, image_encoder=None, unet=None, controlnet=None, scheduler=None,
-                 feature_extractor=None, parallel=None):
+                 feature_extractor=None, parallel=None, round_latents_to_fp16=False):
         """parallel: optional ``parallel.FrameParallel`` -- this process then computes one CFG half / one frame shard
-        of every clip (mofa_video_amd/parallel.py); all ranks must call the pipeline with identical inputs."""
+        of every clip (mofa_video_amd/parallel.py); all ranks must call the pipeline with identical inputs.
+        round_latents_to_fp16: round the latents to fp16 after every Euler step, as the reference's fp16 run does."""
         self.vae, self.image_encoder, self.unet, self.controlnet = vae, image_encoder, unet, controlnet
         self.scheduler, self.feature_extractor = scheduler, feature_extractor
         self.vae_scale_factor = 8
         self.device = unet.device
         self.parallel = parallel
+        self.round_latents_to_fp16 = round_latents_to_fp16
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, unet=None, controlnet=None, device="cuda", variant=None,
+                        **modules):
+        """the call of MOFA-Video-Traj/run_gradio.py:112-116: ``vae/``, ``image_encoder/`` (and ``unet/`` when not given) of
+        a Stable-Video-Diffusion checkpoint directory; ``unet`` / ``controlnet`` (``face_controlnet`` / ``drag_controlnet``
+        for the Hybrid class) are passed in already built, as the reference does.  Other diffusers keyword arguments
+        (``torch_dtype``, ``low_cpu_mem_usage``, ``local_files_only`` ...) are accepted and ignored."""
+        from .clip import CLIPVisionModelWithProjection
+        from .scheduler import EulerDiscreteScheduler
+        from .unet import UNetSpatioTemporalConditionControlNetModel
+        from .vae import AutoencoderKLTemporalDecoder
+        from . import checkpoint
+        root = pretrained_model_name_or_path
+        if unet is None:
+            unet = UNetSpatioTemporalConditionControlNetModel.from_pretrained(root, subfolder="unet", device=device, variant=variant)
+        vae = AutoencoderKLTemporalDecoder.from_pretrained(root, subfolder="vae", device=device, variant=variant)
+        enc = CLIPVisionModelWithProjection.from_pretrained(root, subfolder="image_encoder", device=device, variant=variant)
+        try:
+            sch = EulerDiscreteScheduler(**{k: v for k, v in checkpoint.load_config(checkpoint.resolve_dir(root, "scheduler")).items()
+                                            if k in EulerDiscreteScheduler().config})
+        except OSError:
+            sch = EulerDiscreteScheduler()
+        names = ("face_controlnet", "drag_controlnet", "parallel", "round_latents_to_fp16", "feature_extractor")
+        kw = {k: v for k, v in modules.items() if k in names}
+        if controlnet is not None:
+            kw["controlnet"] = controlnet
+        return cls(vae=vae, image_encoder=enc, unet=unet, scheduler=sch, **kw)
+
+    # ---- pieces of the reference __call__ ---------------------------------------------------------------------------------
     def check_inputs(self, image, height, width):                      # pipeline.py:222-234
         if image is not None and not torch.is_tensor(image) and not isinstance(image, list) and not hasattr(image, "convert"):
             raise ValueError("`image` has to be of type `torch.FloatTensor` or `PIL.Image.Image` or "
                              f"`List[PIL.Image.Image]` but is {type(image)}")
         if height % 8 != 0 or width % 8 != 0:
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+
+    def _check_call(self, batch_size, num_videos_per_prompt, max_guidance_scale, frames_per_forward):
+        if batch_size != 1 or num_videos_per_prompt != 1:
+            raise ValueError("one clip per call (as every reference entry point does)")
+        if not max_guidance_scale > 1.0:
+            raise ValueError("the reference pipeline is only well-defined with classifier-free guidance on")
+        if frames_per_forward > MAX_TEMPORAL_FRAMES:
+            raise ValueError(f"{frames_per_forward} frames per forward pass: the temporal attention kernel handles at most "
+                             f"{MAX_TEMPORAL_FRAMES} (use KeypointFlowControlNetPipeline's window loop for long clips)")
 
     def prepare_latents(self, batch_size, num_frames, num_channels_latents, height, width, generator, latents=None):
         shape = (batch_size, num_frames, num_channels_latents // 2, height // 8, width // 8)
@@ -90,17 +144,16 @@ class FlowControlNetPipeline:
     def _conditioning(self, image, image_embeddings, image_latents, height=None, width=None, noise_aug_strength=0.02,
                       generator=None):
         """image: PIL / tensor in [0, 1] (what the reference's numpy_to_pt yields); either half can be supplied
-        precomputed through the ``image_embeddings`` / ``image_latents`` extensions."""
+        precomputed through the ``image_embeddings`` / ``image_latents`` extensions.  As in the reference the CLIP branch
+        sees the image at its OWN size (pipeline.py:118-122: straight into the 224 x 224 antialiased resize), the VAE branch
+        the ``preprocess(image, height, width)`` result (:338)."""
         dev = self.device
-        image01 = None
-        if image_embeddings is None or image_latents is None:
-            if image is None:
-                raise ValueError("pass `image`, or both image_embeddings=... and image_latents=...")
-            image01 = frontend.image_to_01(image, height, width, dev)
+        if (image_embeddings is None or image_latents is None) and image is None:
+            raise ValueError("pass `image`, or both image_embeddings=... and image_latents=...")
         if image_embeddings is None:
-            image_embeddings = self._encode_image(image01)
+            image_embeddings = self._encode_image(frontend.image_to_01(image, None, None, dev))
         if image_latents is None:
-            image_latents = self._encode_vae_image(image01, noise_aug_strength, generator)
+            image_latents = self._encode_vae_image(frontend.image_to_01(image, height, width, dev), noise_aug_strength, generator)
         emb = image_embeddings.to(dev, torch.float32).reshape(-1, 1, image_embeddings.shape[-1])
         if emb.shape[0] == 1:                                             # :133-139 uncond = zeros
             emb = torch.cat([torch.zeros_like(emb), emb])
@@ -109,6 +162,56 @@ class FlowControlNetPipeline:
             il = torch.cat([torch.zeros_like(il), il])
         return emb, il.contiguous()
 
+    def _condition_image(self, controlnet_condition, height, width):
+        """``self.image_processor.preprocess(controlnet_condition, height=height, width=width)`` (pipeline.py:391): PIL /
+        numpy / tensor, resized, [0, 1] -> [-1, 1] unless the tensor already holds negative values"""
+        if controlnet_condition is None:
+            raise ValueError("`controlnet_condition` is required")
+        return frontend.preprocess(controlnet_condition, height, width, self.device)
+
+    def _round(self, lat):
+        if not self.round_latents_to_fp16:
+            return lat
+        return ops.cast_f16_to_f32(ops.cast_f32_to_f16(lat.contiguous())).reshape(lat.shape)
+
+    def _callback(self, cb, i, t, lat, shape):
+        """callback_on_step_end(self, i, t, {"latents": ...}) may return replacement latents (pipeline.py:503-508)"""
+        if cb is None:
+            return lat
+        out = cb(self, i, t, {"latents": lat.reshape(shape)})
+        if out and "latents" in out:
+            lat = out["latents"].to(self.device, torch.float32).reshape(lat.shape).contiguous()
+        return lat
+
+    def _decode(self, latents_out, T, decode_chunk_size, output_type, sh, stream_chunks=None):
+        """decode_latents + tensor2vid (pipeline.py:513-518).  With several ranks the independent VAE chunks (:204-213) are
+        dealt round-robin: the result is then the list of (first_frame, frames) chunks this rank decoded.  stream_chunks: {chunk
+        index: raw fp32 [n,3,H,W]} already decoded on a side stream (Keypoint loop)."""
+        if output_type == "latent":
+            return latents_out
+        if sh.world == 1:
+            if stream_chunks:
+                parts = []
+                for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
+                    z = latents_out[0, s0:s0 + decode_chunk_size]
+                    parts.append(stream_chunks[ci] if ci in stream_chunks else
+                                 self.vae.decode(z, num_frames=z.shape[0], _prescale=1.0 / self.vae.config.scaling_factor))
+                fr = torch.cat(parts, 0)
+                frames = fr.reshape(-1, T, *fr.shape[1:]).permute(0, 2, 1, 3, 4).float()
+            else:
+                frames = decode_latents(self.vae, latents_out, T, decode_chunk_size)   # fp32 [1,3,T,H,W]
+            return frames if output_type == "raw" else tensor2vid(frames, None, output_type=output_type)
+        frames = []
+        sf = 1.0 / self.vae.config.scaling_factor
+        for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
+            if ci % sh.world == sh.rank:
+                z = latents_out[0, s0:s0 + decode_chunk_size]
+                fr = self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)           # fp32 [n,3,H,W]
+                if output_type != "raw":
+                    fr = tensor2vid(fr.permute(1, 0, 2, 3).unsqueeze(0), None, output_type=output_type)[0]
+                frames.append((s0, fr))
+        return frames
+
     # ---------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def __call__(self, image=None, controlnet_condition=None, controlnet_flow=None, height: int = 576,
@@ -116,7 +219,7 @@ class FlowControlNetPipeline:
                  min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0, fps: int = 7,
                  motion_bucket_id: int = 127, noise_aug_strength: float = 0.02,
                  decode_chunk_size: Optional[int] = None, num_videos_per_prompt: Optional[int] = 1,
-                 generator=None, latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pt",
+                 generator=None, latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pil",
                  callback_on_step_end: Optional[Callable[[int, int, Dict], None]] = None,
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], return_dict: bool = True,
                  controlnet_cond_scale=1.0, batch_size=1, *, image_embeddings=None, image_latents=None):
@@ -124,10 +227,7 @@ class FlowControlNetPipeline:
         num_frames = num_frames if num_frames is not None else unet.config.num_frames
         decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames
         self.check_inputs(image, height, width)
-        if batch_size != 1 or num_videos_per_prompt != 1:
-            raise ValueError("one clip per call (as every reference entry point does)")
-        if not max_guidance_scale > 1.0:
-            raise ValueError("the reference pipeline is only well-defined with classifier-free guidance on")
+        self._check_call(batch_size, num_videos_per_prompt, max_guidance_scale, num_frames)
         h, w = height // 8, width // 8
         T = num_frames
 
@@ -141,19 +241,12 @@ class FlowControlNetPipeline:
         lat = lat.reshape(T, 4, h, w).contiguous()
 
         # adapter condition: identical for both CFG halves (:393-397) -> computed once
-        cond = _to_tensor_image(controlnet_condition, height, width, dev)
+        cond = self._condition_image(controlnet_condition, height, width)
         flow = controlnet_flow.to(dev, torch.float32)
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)   # :430-440
 
-        par = self.parallel
-        lay = par.lay if par is not None else None
-        if lay is not None:
-            assert lay.T == T, "Layout was built for a different frame count"
-        f0, f1 = (lay.f0, lay.f1) if lay is not None else (0, T)
-        Tl = f1 - f0                                                      # frames held by this rank
-        Bl = lay.B_loc if lay is not None else 2                          # CFG halves computed by this rank
-        half = lay.half if lay is not None else None
-        fpar = par if (lay is not None and lay.sharded_frames) else None
+        sh = _Shard(self.parallel, T)
+        f0, f1, Tl, Bl, half, fpar = sh.f0, sh.f1, sh.Tl, sh.Bl, sh.half, sh.fpar
         warped = cn.prepare_condition(cond[:1], flow[:1], frames=(f0, f1))
         lat = lat[f0:f1].contiguous()
         gspan = (max_guidance_scale - min_guidance_scale) / max(T - 1, 1)  # per-frame guidance is linear in the frame
@@ -172,48 +265,48 @@ class FlowControlNetPipeline:
             unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
             noise = unet.forward_tokens(x_loc, c_un, h, w, down_res, mid_res)
             if Bl == 1:
-                noise = par.gather_cfg(noise)                             # both halves of this frame shard
+                noise = sh.par.gather_cfg(noise)                          # both halves of this frame shard
             ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
-            if callback_on_step_end is not None:
-                out = callback_on_step_end(self, i, t, {"latents": lat.reshape(1, Tl, 4, h, w)})
-                if out and "latents" in out:
-                    lat = out["latents"].to(dev, torch.float32).reshape(Tl, 4, h, w).contiguous()
+            lat = self._round(lat)
+            lat = self._callback(callback_on_step_end, i, t, lat, (1, Tl, 4, h, w))
 
         if fpar is not None:                                              # reassemble the clip's latents on every rank
             lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
-        latents_out = lat.reshape(1, T, 4, h, w)
-        if output_type == "latent":
-            frames = latents_out
-        elif lay is None or lay.world == 1:
-            frames = decode_latents(self.vae, latents_out, T, decode_chunk_size)       # fp32 [1,3,T,H,W]
-            if output_type != "raw":                                                   # pipeline.py:518
-                frames = tensor2vid(frames, None, output_type=output_type)
-        else:
-            # VAE chunks are independent (pipeline.py:204-213): dealt round-robin to all ranks; the result is the list
-            # of (first_frame, fp32 [n,3,H,W]) chunks this rank decoded
-            frames = []
-            sf = 1.0 / self.vae.config.scaling_factor
-            for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
-                if ci % lay.world == lay.rank:
-                    z = latents_out[0, s0:s0 + decode_chunk_size]
-                    fr = self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)           # fp32 [n,3,H,W]
-                    if output_type != "raw":
-                        fr = tensor2vid(fr.permute(1, 0, 2, 3).unsqueeze(0), None, output_type=output_type)[0]
-                    frames.append((s0, fr))
+        frames = self._decode(lat.reshape(1, T, 4, h, w), T, decode_chunk_size, output_type, sh)
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
-
 
 
 # =========================================================================================================
 # Hybrid: face (landmark) adapter + drag (trajectory) adapter, residuals blended by the user mask
 # (MOFA-Video-Hybrid/pipeline/pipeline.py:293-320 signature, :443-507 loop, :479-489 blend)
 # =========================================================================================================
+def _resized_masks(mask, height, width, h, w, dev):
+    """user mask [1,1,H,W] nearest-resized to the four residual resolutions (:481, :488); timestep-invariant"""
+    m = mask.to(dev, torch.float32).reshape(1, height, width)
+    masks, hh, ww = {}, h, w
+    for _ in range(4):
+        masks[hh * ww] = ops.resize_nearest_f32(m, hh, ww).reshape(-1).contiguous()
+        hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+    return masks
+
+
+def _blend_residuals(df, mf, dd, md, masks, nframes):
+    """face * m + drag * (1 - m) on all 12 + 1 residuals (:479-489)"""
+    down = []
+    for a, b in zip(df, dd):
+        hw = a.shape[0] // nframes
+        down.append(ops.mask_blend(a, b, masks[hw], hw))
+    hw = mf.shape[0] // nframes
+    return down, ops.mask_blend(mf, md, masks[hw], hw)
+
+
 class HybridFlowControlNetPipeline(FlowControlNetPipeline):
     def __init__(self, vae=None, image_encoder=None, unet=None, face_controlnet=None, drag_controlnet=None,
-                 scheduler=None, feature_extractor=None, parallel=None):
-        super().__init__(vae, image_encoder, unet, face_controlnet, scheduler, feature_extractor, parallel=parallel)
+                 scheduler=None, feature_extractor=None, parallel=None, round_latents_to_fp16=False):
+        super().__init__(vae, image_encoder, unet, face_controlnet, scheduler, feature_extractor, parallel=parallel,
+                         round_latents_to_fp16=round_latents_to_fp16)
         self.face_controlnet, self.drag_controlnet = face_controlnet, drag_controlnet
 
     @torch.no_grad()
@@ -222,7 +315,7 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
                  num_inference_steps: int = 25, min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0,
                  fps: int = 7, motion_bucket_id: int = 127, noise_aug_strength: float = 0.02,
                  decode_chunk_size: Optional[int] = None, num_videos_per_prompt: Optional[int] = 1, generator=None,
-                 latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pt",
+                 latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pil",
                  callback_on_step_end=None, callback_on_step_end_tensor_inputs: List[str] = ["latents"],
                  return_dict: bool = True, ctrl_scale_traj=1.0, ctrl_scale_ldmk=1.0, batch_size=1, *,
                  image_embeddings=None, image_latents=None):
@@ -230,39 +323,28 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
         T = num_frames if num_frames is not None else unet.config.num_frames
         decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else T
         self.check_inputs(image, height, width)
+        self._check_call(batch_size, num_videos_per_prompt, max_guidance_scale, T)
         h, w = height // 8, width // 8
         emb, il = self._conditioning(image, image_embeddings, image_latents, height, width, noise_aug_strength, generator)
         sch.set_timesteps(num_inference_steps)
         timesteps = sch.timesteps
         lat = self.prepare_latents(1, T, unet.config.in_channels, height, width, generator, latents).reshape(T, 4, h, w).contiguous()
-        cond = _to_tensor_image(controlnet_condition, height, width, dev)
+        cond = self._condition_image(controlnet_condition, height, width)
         # frame sharding exactly as in FlowControlNetPipeline.__call__ (2-way CFG x frame shards)
-        par = self.parallel
-        lay = par.lay if par is not None else None
-        if lay is not None:
-            assert lay.T == T, "Layout was built for a different frame count"
-        f0, f1 = (lay.f0, lay.f1) if lay is not None else (0, T)
-        Tl = f1 - f0
-        Bl = lay.B_loc if lay is not None else 2
-        half = lay.half if lay is not None else None
-        fpar = par if (lay is not None and lay.sharded_frames) else None
+        sh = _Shard(self.parallel, T)
+        f0, f1, Tl, Bl, half, fpar = sh.f0, sh.f1, sh.Tl, sh.Bl, sh.half, sh.fpar
         cf = face.prepare_condition(cond[:1], controlnet_flow.to(dev, torch.float32)[:1], landmarks[:1], frames=(f0, f1))
         cd = drag.prepare_condition(cond[:1], drag_flow.to(dev, torch.float32)[:1], frames=(f0, f1))
         lat = lat[f0:f1].contiguous()
         gspan = (max_guidance_scale - min_guidance_scale) / max(T - 1, 1)
         g0, g1 = min_guidance_scale + gspan * f0, min_guidance_scale + gspan * (f1 - 1)
-        # user mask, nearest-resized to every residual resolution (:481, :488) -- timestep-invariant
-        m = mask.to(dev, torch.float32).reshape(1, height, width)
-        masks = {}
-        hh, ww = h, w
-        for _ in range(4):
-            masks[hh * ww] = ops.resize_nearest_f32(m, hh, ww).reshape(-1).contiguous()
-            hh, ww = (hh - 1) // 2 + 1, (ww - 1) // 2 + 1
+        masks = _resized_masks(mask, height, width, h, w, dev)
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
         c_f, c_d, c_u = Ctx(Bl, Tl), Ctx(Bl, Tl), Ctx(Bl, Tl)
         rows = Tl * h * w
         x_in = torch.zeros((2 * rows, unet.in_ld), dtype=torch.float16, device=dev)
         x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
+        self._num_timesteps = len(timesteps)
         for i, t in enumerate(timesteps):
             sigma, sigma_next = sch.sigma_pair(i)
             ops.prepare_model_input(lat, il, x_in, sigma)
@@ -270,36 +352,17 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
             df, mf = face.forward_tokens(x_loc, c_f, h, w, cf, ctrl_scale_ldmk)
             drag.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_d, half=half, par=fpar)
             dd, md = drag.forward_tokens(x_loc, c_d, h, w, cd, ctrl_scale_traj)
-            down = []
-            for a, b in zip(df, dd):
-                hw = a.shape[0] // (Bl * Tl)
-                down.append(ops.mask_blend(a, b, masks[hw], hw))
-            hw = mf.shape[0] // (Bl * Tl)
-            mid = ops.mask_blend(mf, md, masks[hw], hw)
+            down, mid = _blend_residuals(df, mf, dd, md, masks, Bl * Tl)
             unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_u, half=half, par=fpar)
             noise = unet.forward_tokens(x_loc, c_u, h, w, down, mid)
             if Bl == 1:
-                noise = par.gather_cfg(noise)
+                noise = sh.par.gather_cfg(noise)
             ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
+            lat = self._round(lat)
+            lat = self._callback(callback_on_step_end, i, t, lat, (1, Tl, 4, h, w))
         if fpar is not None:
             lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
-        latents_out = lat.reshape(1, T, 4, h, w)
-        if output_type == "latent":
-            frames = latents_out
-        elif lay is None or lay.world == 1:
-            frames = decode_latents(self.vae, latents_out, T, decode_chunk_size)
-            if output_type != "raw":
-                frames = tensor2vid(frames, None, output_type=output_type)
-        else:                                             # VAE chunks dealt round-robin, as in FlowControlNetPipeline
-            frames = []
-            sf = 1.0 / self.vae.config.scaling_factor
-            for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
-                if ci % lay.world == lay.rank:
-                    z = latents_out[0, s0:s0 + decode_chunk_size]
-                    fr = self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)
-                    if output_type != "raw":
-                        fr = tensor2vid(fr.permute(1, 0, 2, 3).unsqueeze(0), None, output_type=output_type)[0]
-                    frames.append((s0, fr))
+        frames = self._decode(lat.reshape(1, T, 4, h, w), T, decode_chunk_size, output_type, sh)
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
@@ -317,90 +380,168 @@ def window_views(num_frames, window_size, stride):
 
 
 class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
+    """The window loop of the reference's long-video pipeline.  Two extensions beyond it (new work, BASELINE config 5):
+    * hybrid control inside the windows: built with a ``drag_controlnet`` and called with ``drag_flow`` / ``mask``, every
+      window runs the landmark adapter AND the trajectory adapter and blends their residuals by the mask, exactly as
+      ``HybridFlowControlNetPipeline`` does per clip (Hybrid/pipeline/pipeline.py:479-489);
+    * the VAE decode overlaps the last denoise step: in that step the windows finish in order, so every decode chunk whose
+      frames are final is decoded on a second HIP stream while the remaining windows are still being stepped; with several
+      ranks (``parallel.WindowParallel``) the chunks are dealt round-robin over the ranks instead."""
+
+    def __init__(self, vae=None, image_encoder=None, unet=None, controlnet=None, scheduler=None, feature_extractor=None,
+                 parallel=None, round_latents_to_fp16=False, drag_controlnet=None, overlap_decode=True):
+        super().__init__(vae, image_encoder, unet, controlnet, scheduler, feature_extractor, parallel=parallel,
+                         round_latents_to_fp16=round_latents_to_fp16)
+        self.drag_controlnet = drag_controlnet
+        self.overlap_decode = overlap_decode
+
     @torch.no_grad()
     def __call__(self, image=None, controlnet_condition=None, controlnet_flow=None, landmarks=None, window_size: int = 25,
                  stride: int = 12, height: int = 576, width: int = 1024, num_frames: Optional[int] = None,
                  num_inference_steps: int = 25, min_guidance_scale: float = 1.0, max_guidance_scale: float = 3.0,
                  fps: int = 7, motion_bucket_id: int = 127, noise_aug_strength: float = 0.02,
                  decode_chunk_size: Optional[int] = None, num_videos_per_prompt: Optional[int] = 1, generator=None,
-                 latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pt",
+                 latents: Optional[torch.FloatTensor] = None, output_type: Optional[str] = "pil",
                  callback_on_step_end=None, callback_on_step_end_tensor_inputs: List[str] = ["latents"],
                  return_dict: bool = True, controlnet_cond_scale=1.0, batch_size=1, *, image_embeddings=None,
-                 image_latents=None):
-        unet, cn, sch, dev = self.unet, self.controlnet, self.scheduler, self.device
+                 image_latents=None, drag_flow=None, mask=None, ctrl_scale_traj=1.0):
+        unet, cn, drag, sch, dev = self.unet, self.controlnet, self.drag_controlnet, self.scheduler, self.device
         N = num_frames if num_frames is not None else unet.config.num_frames
         Tw = window_size
         decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else N
         self.check_inputs(image, height, width)
+        self._check_call(batch_size, num_videos_per_prompt, max_guidance_scale, Tw)
+        if N < Tw:
+            raise ValueError(f"num_frames ({N}) must be at least window_size ({Tw})")
+        if not 0 < stride < Tw:
+            raise ValueError(f"stride ({stride}) must lie in (0, window_size = {Tw}): consecutive windows have to overlap")
+        hybrid = drag_flow is not None
+        if hybrid and (drag is None or mask is None):
+            raise ValueError("hybrid control needs a drag_controlnet (constructor) and a mask")
         h, w = height // 8, width // 8
         emb, il = self._conditioning(image, image_embeddings, image_latents, height, width, noise_aug_strength, generator)
         sch.set_timesteps(num_inference_steps)
         timesteps = sch.timesteps
         lat = self.prepare_latents(1, N, unet.config.in_channels, height, width, generator, latents).reshape(N, 4, h, w).contiguous()
-        cond = _to_tensor_image(controlnet_condition, height, width, dev)
+        cond = self._condition_image(controlnet_condition, height, width)
         flow = controlnet_flow.to(dev, torch.float32)
+        dflow = drag_flow.to(dev, torch.float32) if hybrid else None
         views = window_views(N, Tw, stride)
         # adapter state per DISTINCT window is timestep-invariant: computed once per clip (the reference recomputes it
         # every step; its last view often repeats the previous one -- SURVEY 3.5 -- and is computed once here)
-        conds = {}
+        conds, dconds = {}, {}
         for (t0, t1) in views:
             if (t0, t1) not in conds:
                 lm = torch.cat([landmarks[:, 0:1], landmarks[:, t0:t1]], dim=1)
                 conds[(t0, t1)] = cn.prepare_condition(cond[:1], flow[:1, t0 - 1:t1 - 1], lm)
+                if hybrid:
+                    dconds[(t0, t1)] = drag.prepare_condition(cond[:1], dflow[:1, t0 - 1:t1 - 1])
+        masks = _resized_masks(mask, height, width, h, w, dev) if hybrid else None
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
-        ctxs = {v: (Ctx(2, Tw), Ctx(2, Tw)) for v in conds}
+        ctxs = {v: (Ctx(2, Tw), Ctx(2, Tw), Ctx(2, Tw)) for v in conds}
         distinct = list(conds)                                                     # distinct windows, in view order
         wpar = self.parallel                                                       # parallel.WindowParallel or None
+        world, rank = (wpar.world, wpar.rank) if wpar is not None else (1, 0)
         x_in = torch.zeros((2 * Tw * h * w, unet.in_ld), dtype=torch.float16, device=dev)
         value = torch.empty_like(lat)
-        fsz = 4 * h * w
+        # the views that cover each frame, and the last of them in processing order: a frame is final once that one is merged
+        last_view_of = [max(idx for idx, (t0, t1) in enumerate(views) if (0 if idx == 0 else t0) <= f < t1) for f in range(N)]
+        side = torch.cuda.Stream(device=dev) if (self.overlap_decode and output_type != "latent" and world == 1) else None
+        stream_chunks = {}
+        self._num_timesteps = len(timesteps)
         for i, t in enumerate(timesteps):
             sigma, sigma_next = sch.sigma_pair(i)
+            last_step = i == len(timesteps) - 1
             count = [0] * N
             touched = [False] * N
-            done = {}
+            overlap = last_step and side is not None and wpar is None
+            # every window of a step reads the latents of the PREVIOUS step; when frames are finalised while later windows
+            # of the (last) step still run, those windows read a snapshot
+            lat_in = lat.clone() if overlap else lat
 
             def step_window(t0, t1):
-                lw = torch.cat([lat[0:1], lat[t0:t1]], dim=0).contiguous()            # frame 0 + window frames
+                lw = torch.cat([lat_in[0:1], lat_in[t0:t1]], dim=0).contiguous()      # frame 0 + window frames
                 ops.prepare_model_input(lw, il, x_in, sigma)
-                c_cn, c_un = ctxs[(t0, t1)]
+                c_cn, c_dr, c_un = ctxs[(t0, t1)]
                 cn.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_cn)
                 down, mid = cn.forward_tokens(x_in, c_cn, h, w, conds[(t0, t1)], controlnet_cond_scale)
+                if hybrid:
+                    drag.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_dr)
+                    dd, md = drag.forward_tokens(x_in, c_dr, h, w, dconds[(t0, t1)], ctrl_scale_traj)
+                    down, mid = _blend_residuals(down, mid, dd, md, masks, 2 * Tw)
                 unet.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_un)
                 noise = unet.forward_tokens(x_in, c_un, h, w, down, mid)
                 ops.cfg_euler_step_(lw, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
                 return lw
+
+            def merge(idx, lw):
+                """value[0:t1] += lw (first view) / value[t0:t1] += lw[1:] (others)   (:502-507)"""
+                t0, t1 = views[idx]
+                if idx == 0 and t0 != 1:
+                    raise ValueError("the first window must start at frame 1")
+                dst0, src0 = (0, 0) if idx == 0 else (t0, 1)
+                for k in range(t1 - dst0):
+                    f = dst0 + k
+                    ops.axpby_f32_(lw[src0 + k].reshape(-1), value[f].reshape(-1), 1.0, 1.0 if touched[f] else 0.0)
+                    touched[f] = True
+                    count[f] += 1
+
+            def finalize(frames):
+                """latents = where(count > 0, value / count, value) (:511; value is 0 where no window landed)"""
+                for f in frames:
+                    if count[f]:
+                        ops.axpby_f32_(value[f].reshape(-1), lat[f].reshape(-1), 1.0 / count[f], 0.0)
+                    else:
+                        lat[f].zero_()
+
+            done = {}
             if wpar is None:
-                for key in distinct:
-                    done[key] = step_window(*key)
+                frontier = 0                                                          # frames [0, frontier) are final (last step)
+                for idx, (t0, t1) in enumerate(views):
+                    if (t0, t1) not in done:
+                        done[(t0, t1)] = step_window(t0, t1)
+                    merge(idx, done[(t0, t1)])
+                    if overlap and idx < len(views) - 1:
+                        # every frame whose last covering view is merged can be averaged now; whole decode chunks below the
+                        # frontier go to the second stream while the next windows run
+                        newf = frontier
+                        while newf < N and last_view_of[newf] <= idx:
+                            newf += 1
+                        if newf > frontier:
+                            finalize(range(frontier, newf))
+                            lat_r = self._round(lat)
+                            ready = torch.cuda.Event()
+                            ready.record()
+                            for ci, s0 in enumerate(range(0, N, decode_chunk_size)):
+                                s1 = min(s0 + decode_chunk_size, N)
+                                if ci not in stream_chunks and s1 <= newf:
+                                    with torch.cuda.stream(side):
+                                        side.wait_event(ready)
+                                        z = lat_r[s0:s1]
+                                        stream_chunks[ci] = self.vae.decode(z, num_frames=s1 - s0,
+                                                                            _prescale=1.0 / self.vae.config.scaling_factor)
+                            frontier = newf
+                finalize(range(frontier, N))
             else:                                         # window-parallel: one window per rank and round
                 for rnd in wpar.rounds(distinct):
-                    mine = rnd[wpar.rank]
+                    mine = rnd[rank]
                     lw = step_window(*mine) if mine is not None else torch.zeros((Tw,) + tuple(lat.shape[1:]),
-                                                                               dtype=lat.dtype, device=dev)
+                                                                                dtype=lat.dtype, device=dev)
                     for key, got in zip(rnd, wpar.gather(lw)):
                         if key is not None:
                             done[key] = got
-            for idx, (t0, t1) in enumerate(views):
-                lw = done[(t0, t1)]
-                # value[0:t1] += lw (first view) / value[t0:t1] += lw[1:] (others)   (:502-507)
-                dst0, src0 = (0, 0) if idx == 0 else (t0, 1)
-                if idx == 0 and t0 != 1:
-                    raise ValueError("the first window must start at frame 1")
-                for k in range(t1 - dst0):
-                    f = dst0 + k
-                    src = lw[src0 + k].reshape(-1)
-                    dstv = value[f].reshape(-1)
-                    ops.axpby_f32_(src, dstv, 1.0, 1.0 if touched[f] else 0.0)
-                    touched[f] = True
-                    count[f] += 1
-            for f in range(N):                                                         # latents = value / count (:511)
-                if count[f]:
-                    ops.axpby_f32_(value[f].reshape(-1), lat[f].reshape(-1), 1.0 / count[f], 0.0)
-        latents_out = lat.reshape(1, N, 4, h, w)
-        frames = latents_out if output_type == "latent" else decode_latents(self.vae, latents_out, N, decode_chunk_size)
-        if output_type not in ("latent", "raw"):
-            frames = tensor2vid(frames, None, output_type=output_type)
+                for idx, (t0, t1) in enumerate(views):
+                    merge(idx, done[(t0, t1)])
+                finalize(range(N))
+            lat = self._round(lat)
+            lat = self._callback(callback_on_step_end, i, t, lat, (1, N, 4, h, w))
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            if callback_on_step_end is not None:
+                stream_chunks = {}                        # a callback may have replaced the latents after the last step
+        sh = _Shard(None, N)
+        sh.world, sh.rank = world, rank
+        frames = self._decode(lat.reshape(1, N, 4, h, w), N, decode_chunk_size, output_type, sh, stream_chunks)
         if not return_dict:
             return frames, controlnet_flow
         return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)

@@ -66,6 +66,16 @@ class UNetSpatioTemporalConditionControlNetModel:
         """Build from any torch module with the reference parameter names (e.g. a loaded checkpoint)."""
         return cls(module.state_dict(), getattr(module, "config", None), device)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", variant=None, **unused):
+        """``config.json`` + ``diffusion_pytorch_model.safetensors`` of a checkpoint directory, as
+        MOFA-Video-Traj/run_gradio.py:98-104 loads the SVD-XT UNet (``subfolder="unet"``); extra diffusers keyword
+        arguments (``low_cpu_mem_usage``, ``torch_dtype`` ...) are accepted and ignored: storage is always fp16"""
+        from . import checkpoint
+        path = checkpoint.resolve_dir(pretrained_model_name_or_path, subfolder)
+        cfg = {k: v for k, v in checkpoint.load_config(path).items() if k in DEFAULT_CONFIG}
+        return cls(checkpoint.load_state_dict(path, variant), cfg, device)
+
     # ------------------------------------------------------------------------------------------------
     def make_ctx(self, timestep, encoder_hidden_states, added_time_ids, B, T, base=None, half=None, par=None):
         """B, T = LOCAL batch / frame counts.  half: global CFG-half index when this rank computes one half only

@@ -183,6 +183,15 @@ class AutoencoderKLTemporalDecoder:
     def from_module(cls, module, device="cuda"):
         return cls(module.state_dict(), None, device)
 
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder=None, device="cuda", variant=None, **unused):
+        """``vae/`` of the SVD-XT checkpoint directory (loaded by ``FlowControlNetPipeline.from_pretrained`` in the reference)"""
+        from . import checkpoint
+        path = checkpoint.resolve_dir(pretrained_model_name_or_path, subfolder)
+        keys = ("block_out_channels", "layers_per_block", "latent_channels", "scaling_factor", "force_upcast")
+        cfg = {k: v for k, v in checkpoint.load_config(path).items() if k in keys}
+        return cls(checkpoint.load_state_dict(path, variant), cfg, device)
+
     def decode(self, z, num_frames=1, _prescale=1.0):
         """z [n, 4, h, w] (n = batch*num_frames, one temporal group of num_frames) -> fp32 [n, 3, 8h, 8w]"""
         n, Cz, h, w = z.shape

@@ -120,8 +120,12 @@ def window_views(num_frames, window_size, stride):
 @torch.no_grad()
 def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, image_embeddings, controlnet_condition,
                           controlnet_flow, landmarks, window_size=25, stride=12, num_inference_steps=25,
-                          min_guidance_scale=1.0, max_guidance_scale=3.0, controlnet_cond_scale=1.0):
-    """latents [1,N,4,h,w]; controlnet_flow [1,N-1,2,H,W]; landmarks [1,N,3,H,W]; ``controlnet`` = landmark adapter."""
+                          min_guidance_scale=1.0, max_guidance_scale=3.0, controlnet_cond_scale=1.0,
+                          drag_controlnet=None, drag_flow=None, mask=None, ctrl_scale_traj=1.0):
+    """latents [1,N,4,h,w]; controlnet_flow [1,N-1,2,H,W]; landmarks [1,N,3,H,W]; ``controlnet`` = landmark adapter.
+    drag_controlnet / drag_flow / mask: BASELINE config 5's "hybrid control" inside the windows -- no reference file runs
+    it; it composes the window loop above with the Hybrid step's residual blend (Hybrid/pipeline/pipeline.py:479-489)."""
+    import torch.nn.functional as F
     num_frames = latents.shape[1]
     scheduler.set_timesteps(num_inference_steps)
     timesteps = scheduler.timesteps
@@ -130,6 +134,8 @@ def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, i
     controlnet_condition = torch.cat([controlnet_condition] * 2)
     controlnet_flow = torch.cat([controlnet_flow] * 2)
     landmarks = torch.cat([landmarks] * 2)
+    if drag_controlnet is not None:
+        drag_flow = torch.cat([drag_flow] * 2)
     guidance_scale = torch.linspace(min_guidance_scale, max_guidance_scale, window_size).unsqueeze(0)
     guidance_scale = guidance_scale.to(latents.dtype)[(...,) + (None,) * 3]
     added_time_ids = make_added_time_ids(latents.dtype)
@@ -151,6 +157,17 @@ def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, i
                                          controlnet_cond=controlnet_condition, controlnet_flow=fl, landmarks=lm,
                                          added_time_ids=added_time_ids, conditioning_scale=controlnet_cond_scale,
                                          return_dict=False)
+            if drag_controlnet is not None:
+                dd, md, _, _ = drag_controlnet(x, t, encoder_hidden_states=image_embeddings,
+                                               controlnet_cond=controlnet_condition,
+                                               controlnet_flow=drag_flow[:, (t0 - 1):(t1 - 1)], added_time_ids=added_time_ids,
+                                               conditioning_scale=ctrl_scale_traj, return_dict=False)
+                blended = []
+                for a_, b_ in zip(down, dd):
+                    m_ = F.interpolate(mask, a_.shape[-2:], mode='nearest')
+                    blended.append(a_ * m_ + b_ * (1 - m_))
+                m_ = F.interpolate(mask, mid.shape[-2:], mode='nearest')
+                down, mid = blended, mid * m_ + md * (1 - m_)
             noise_pred = unet(x, t, encoder_hidden_states=image_embeddings, down_block_additional_residuals=down,
                               mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
             u, c = noise_pred.chunk(2)
