@@ -1,0 +1,100 @@
+"""``draw_landmarks`` / pose images (mofa_video_amd/landmarks.py; reference MOFA-Video-Keypoint/utils/utils.py:7-46,
+mofa_keypoint.py:299-316).  OpenCV cannot be imported here, so the restated ``cv2.line(thickness=2)`` is pinned by vectors
+derived BY HAND from the published algorithm (cv::ThickLine: quad of half-width 1.0 px filled by FillConvexPoly + a filled
+radius-1 circle, a "plus", at both end points) and by structural properties; the bilinear resize against torch's
+``F.interpolate(align_corners=False)``, which uses the same half-pixel convention."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from mofa_video_amd import landmarks as L
+
+
+def _pixels(img):
+    ys, xs = np.nonzero(img[:, :, 0])
+    return set(zip(xs.tolist(), ys.tolist()))
+
+
+def _draw(p1, p2, h=16, w=16):
+    return L.line(np.zeros((h, w, 3)), p1, p2, (7, 8, 9), 2)
+
+
+def test_horizontal_line_hand_derived():
+    # d = (0, -1.0 px): quad (2,1) (2,3) (6,3) (6,1) -> rows 1..3 x columns 2..6; end-point pluses add (1,2) and (7,2)
+    want = {(x, y) for x in range(2, 7) for y in range(1, 4)} | {(1, 2), (7, 2)}
+    img = _draw((2, 2), (6, 2))
+    assert _pixels(img) == want
+    assert (img[2, 4] == np.array([7.0, 8.0, 9.0])).all()
+    assert _pixels(_draw((6, 2), (2, 2))) == want                      # direction does not matter
+
+
+def test_vertical_line_hand_derived():
+    want = {(x, y) for x in range(2, 5) for y in range(1, 9)} | {(3, 0), (3, 9)}
+    assert _pixels(_draw((3, 1), (3, 8))) == want
+
+
+def test_zero_length_line_is_the_radius_1_circle():
+    # r == 0: no quad; Circle(radius = (65536 + 32768) >> 16 = 1) = the 5-pixel plus
+    assert _pixels(_draw((5, 5), (5, 5))) == {(5, 4), (4, 5), (5, 5), (6, 5), (5, 6)}
+
+
+def test_line_clipped_at_the_border_hand_derived():
+    # quad (-2,2) (-2,4) (4,4) (4,2) clipped to columns 0..4; the left plus lies outside, the right one adds (5,3)
+    want = {(x, y) for x in range(0, 5) for y in range(2, 5)} | {(5, 3)}
+    assert _pixels(_draw((-2, 3), (4, 3))) == want
+    assert _pixels(_draw((3, -4), (3, -2))) == set()                   # entirely outside
+
+
+def test_diagonal_line_properties():
+    img = _draw((2, 2), (9, 9))
+    px = _pixels(img)
+    assert px == {(y, x) for (x, y) in px}                             # 45 degrees: symmetric under x <-> y
+    assert {(k, k) for k in range(2, 10)} <= px                        # the centre line itself
+    assert all(abs(x - y) <= 2 for x, y in px)                          # half-width 1 px along the normal (+ rounding)
+    cols = [sum(1 for (x, y) in px if x == c) for c in range(3, 9)]
+    assert min(cols) >= 3 and max(cols) <= 5
+    # a shallow line: every column between the end points holds a contiguous run of 2..4 pixels
+    img = _draw((1, 1), (12, 3), w=20)
+    for c in range(1, 13):
+        rows = sorted(y for (x, y) in _pixels(img) if x == c)
+        assert 2 <= len(rows) <= 4 and rows == list(range(rows[0], rows[-1] + 1)), (c, rows)
+
+
+def _face(seed=0, h=320, w=320):
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0, 2 * np.pi, 68, endpoint=False)
+    return np.stack([w / 2 + 0.3 * w * np.cos(t), h / 2 + 0.38 * h * np.sin(t)], 1) + rng.normal(0, 3, (68, 2))
+
+
+def test_draw_landmarks_canvas():
+    kp = _face()
+    img = L.draw_landmarks(kp, 320, 320)
+    assert img.shape == (320, 320, 3) and img.dtype == np.float64
+    colours = {tuple(c) for c in img.reshape(-1, 3).tolist()}
+    assert colours <= {(0.0, 0.0, 0.0)} | {tuple(float(v) for v in c) for _, _, c in L.PARTS}
+    assert len(colours) >= 12                                          # nearly every part is visible
+    for _name, idx, colour in L.PARTS[-3:]:                            # drawn last: their end points keep their colour
+        x, y = int(kp[idx[-1] - 1][0]), int(kp[idx[-1] - 1][1])
+        if _name == L.PARTS[-1][0]:
+            assert tuple(img[y, x]) == tuple(float(v) for v in colour)
+    assert 2000 < np.count_nonzero(img[:, :, 1]) < 12000
+    assert L.draw_landmarks(kp + 1000.0, 320, 320).sum() == 0          # off-canvas landmarks draw nothing
+
+
+def test_resize_linear_matches_half_pixel_bilinear():
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 250, (40, 56, 3))
+    assert np.array_equal(L.resize_linear(img, 56, 40), img)
+    for (w, h) in [(112, 80), (28, 20), (75, 33)]:
+        got = L.resize_linear(img, w, h)
+        ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(h, w), mode="bilinear",
+                            align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert got.shape == (h, w, 3)
+        assert np.abs(got - ref).max() < 250 * 2e-6, (w, h, np.abs(got - ref).max())   # fp32 weights vs fp64
+
+
+def test_pose_images_for_the_pipelines():
+    kp = np.stack([_face(s, 256, 384) * np.array([384 / 320, 256 / 320]) for s in range(3)])
+    pose = L.pose_images(kp, 256, 384)
+    assert tuple(pose.shape) == (1, 3, 3, 256, 384) and pose.dtype == torch.float32
+    assert float(pose.min()) == 0.0 and 0.5 < float(pose.max()) <= 250 / 255 + 1e-6
