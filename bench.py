@@ -33,7 +33,6 @@ sys.path.insert(0, ROOT)
 T, H, W, STEPS, CHUNK = 25, 576, 1024, 25, 8
 if os.environ.get("MOFA_BENCH_DENOISE_STEPS"):   # functional checks only -- a line produced with this set is not a result
     STEPS = int(os.environ["MOFA_BENCH_DENOISE_STEPS"])
-CLIP_TFLOP = 5638.0          # single-adapter clip, reference schedule (adapter work per step)
 MFMA_PEAK_TFLOPS = 2500.0    # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
@@ -83,6 +82,115 @@ def build_pipeline(device, seed=0, frontend=False):
     unet, cn, vae = mods[:3]
     return FlowControlNetPipeline(vae=vae, image_encoder=mods[3] if frontend else None, unet=unet, controlnet=cn,
                                   scheduler=EulerDiscreteScheduler())
+
+
+def synthetic_landmark_inputs(device, n_frames=T, seed=43):
+    """68 landmarks on a face-sized ellipse, every point drifting <= 20 px over the clip; the
+    dense flow is 68 Gaussian bumps (sigma 12 px) carrying those displacements (what CMP produces from the sparse landmark
+    flow), the pose images are the reference's polyline drawing of the landmarks (mofa_video_amd/landmarks.py)."""
+    import numpy as np
+    from mofa_video_amd.landmarks import pose_images
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    th = torch.linspace(0, 2 * 3.14159265, 69)[:68]
+    base = torch.stack([W / 2 + 0.16 * W * torch.cos(th), H / 2 + 0.30 * H * torch.sin(th)], 1)      # [68, 2] (x, y)
+    drift = (torch.rand(68, 2, generator=g) * 2 - 1) * 20.0
+    lm = torch.stack([base + drift * (f / max(n_frames - 1, 1)) for f in range(n_frames)])           # [N, 68, 2]
+    ys = torch.arange(H, dtype=torch.float32, device=device).view(H, 1)
+    xs = torch.arange(W, dtype=torch.float32, device=device).view(1, W)
+    flow = torch.zeros(1, n_frames - 1, 2, H, W, device=device)
+    wsum = torch.zeros(H, W, device=device)
+    bumps = []
+    for k in range(68):
+        b = torch.exp(-((xs - float(base[k, 0])) ** 2 + (ys - float(base[k, 1])) ** 2) / (2 * 12.0 ** 2))
+        bumps.append(b)
+        wsum += b
+    for i in range(n_frames - 1):
+        fx = torch.zeros(H, W, device=device)
+        fy = torch.zeros(H, W, device=device)
+        for k in range(68):
+            d = lm[i + 1, k] - lm[0, k]
+            fx += bumps[k] * float(d[0])
+            fy += bumps[k] * float(d[1])
+        flow[0, i, 0], flow[0, i, 1] = fx / wsum.clamp_min(1.0), fy / wsum.clamp_min(1.0)
+    return dict(flow=flow, landmarks=pose_images(np.asarray(lm), H, W).to(device))
+
+
+def synthetic_mask(device):
+    """config 4: binary mask [1,1,H,W], a centred rectangle covering 25 % of the area (1 = landmark adapter)"""
+    m = torch.zeros(1, 1, H, W, device=device)
+    m[:, :, H // 4:3 * H // 4, W // 4:3 * W // 4] = 1.0
+    return m
+
+
+def build_config_pipeline(device, config, seed=0):
+    """configs 3 / 4 / 5 reuse config 2's UNet / VAE / front end and add the landmark adapter (+ keep the trajectory one)"""
+    from mofa_video_amd import schema
+    from mofa_video_amd.adapter import LandmarkFlowControlNet
+    from mofa_video_amd.pipeline import HybridFlowControlNetPipeline, KeypointFlowControlNetPipeline
+    base = build_pipeline(device, seed=seed, frontend=True)
+    if config == 2:
+        return base
+    sd = schema.synthetic_state_dict(schema.ldmk_controlnet_schema(), seed=seed + 7, device=device)
+    face = LandmarkFlowControlNet(sd, None, device)
+    del sd
+    torch.cuda.empty_cache()
+    common = dict(vae=base.vae, image_encoder=base.image_encoder, unet=base.unet, scheduler=base.scheduler)
+    if config == 3:
+        return KeypointFlowControlNetPipeline(controlnet=face, **common)
+    if config == 4:
+        return HybridFlowControlNetPipeline(face_controlnet=face, drag_controlnet=base.controlnet, **common)
+    return KeypointFlowControlNetPipeline(controlnet=face, drag_controlnet=base.controlnet, **common)
+
+
+LONG_FRAMES = 97      # config 5: "4 x 25-frame chunks": window 25, stride 12 -> 7 full windows cover 97 frames
+
+
+def config_inputs(device, config, seed=42):
+    inp = synthetic_inputs(device, seed)
+    if config == 2:
+        return inp
+    n = LONG_FRAMES if config == 5 else T
+    lmk = synthetic_landmark_inputs(device, n)
+    if config == 5:                                           # the trajectory hint of config 2 stretched over the long clip
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        inp["latents"] = torch.randn(1, n, 4, H // 8, W // 8, generator=g).to(device)
+        f = torch.arange(1, n, device=device, dtype=torch.float32).view(1, n - 1, 1, 1, 1) / (n - 1)
+        inp["drag_flow"] = inp["flow"][:, -1:].repeat(1, n - 1, 1, 1, 1) * f
+    else:
+        inp["drag_flow"] = inp["flow"]
+    inp["flow"], inp["landmarks"] = lmk["flow"], lmk["landmarks"]
+    inp["mask"] = synthetic_mask(device)
+    return inp
+
+
+def run_config(pipe, inp, config):
+    """one clip of BASELINE.json configs[config - 1] through the reference call of that configuration"""
+    gen = torch.Generator().manual_seed(1234)
+    common = dict(controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=H, width=W,
+                  num_inference_steps=STEPS, decode_chunk_size=CHUNK, latents=inp["latents"], output_type="pt", generator=gen)
+    if config == 2:
+        return run_clip(pipe, inp)
+    if config == 3:      # Keypoint, 25 frames = one window (MOFA-Video-Keypoint/mofa_keypoint.py:346-360)
+        return pipe(inp["image"], landmarks=inp["landmarks"], window_size=T, stride=T // 2, num_frames=T, **common).frames
+    if config == 4:      # Hybrid (MOFA-Video-Hybrid/run_gradio_audio_driven.py:452-471)
+        return pipe(inp["image"], landmarks=inp["landmarks"], drag_flow=inp["drag_flow"], mask=inp["mask"], num_frames=T,
+                    **common).frames
+    return pipe(inp["image"], landmarks=inp["landmarks"], window_size=T, stride=T // 2, num_frames=LONG_FRAMES,
+                drag_flow=inp["drag_flow"], mask=inp["mask"], **common).frames
+
+
+WORKLOADS = {
+    2: "MOFA-Video-Traj, 25-frame 576x1024, 25 denoise steps + temporal VAE decode (chunk 8), single trajectory hint, "
+       "SVD-XT UNet + MOFA-Adapter, CFG 1->3, seeded random weights in the reference checkpoint layout",
+    3: "MOFA-Video-Keypoint, 25-frame 576x1024, 25 denoise steps + temporal VAE decode (chunk 8), landmark-driven dense flow "
+       "(68 landmarks, polyline pose images), SVD-XT UNet + landmark MOFA-Adapter (occlusion matting), seeded random weights",
+    4: "MOFA-Video-Hybrid, 25-frame 576x1024, 25 denoise steps + temporal VAE decode (chunk 8), trajectory + landmark "
+       "dual adapter blended by a 25 % mask, SVD-XT UNet, seeded random weights",
+    5: "Long video: 97 frames (4 x 25-frame chunks: 7 windows of 25, stride 12) 576x1024, 25 denoise steps, hybrid control "
+       "in every window, overlap-averaged latents, VAE decode (chunk 8) overlapped with the last step, seeded random weights",
+}
+# SURVEY.md 8(d): single adapter 218.58 TFLOP per step + 173.57 decode; dual adapter 277.27 per step
+CLIP_TFLOPS = {2: 5638.0, 3: 5638.0, 4: 7105.0, 5: 7 * 25 * 277.27 + 173.57 * LONG_FRAMES / 25.0}
 
 
 def run_clip(pipe, inp):
@@ -166,6 +274,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[config - 1]: 2 = Traj (the headline metric's configuration, default), "
+                         "3 = Keypoint, 4 = Hybrid, 5 = 97-frame long video with hybrid control (about a minute per clip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the "
                     "single-GPU functional check of the multi-process path, see tests/README in DESIGN.md)")
     ap.add_argument("--mode", choices=["shard", "replicas"], default="shard",
@@ -195,13 +306,20 @@ def main():
 
     from mofa_video_amd import lib, ops
     lib.load()                                              # fails loudly without the HIP library
-    pipe = build_pipeline(dev, seed=0, frontend=True)
+    cfg = args.config
+    pipe = build_config_pipeline(dev, cfg, seed=0)
     mode = args.mode if world > 1 else "single"
-    mode_note = ""
+    if mode == "shard" and cfg == 3:
+        mode = "replicas"                                   # one 25-frame window: nothing to shard in the window loop
     if mode == "shard":
-        # every rank must see the same clip; partition = mofa_video_amd/parallel.py
-        from mofa_video_amd.parallel import FrameParallel, Layout, TorchComm
-        try:
+        # every rank must see the same clip; partition = mofa_video_amd/parallel.py.  A failure here is an error: a
+        # strong-scaling request must never silently turn into independent replicas
+        from mofa_video_amd.parallel import FrameParallel, Layout, TorchComm, WindowParallel
+        if cfg == 5:                                        # long video: the windows of a step are dealt to the ranks
+            comm = TorchComm(lambda r: Layout(1, 0, T))
+            pipe.parallel = WindowParallel(comm, rank, world)
+            comm.all_gather_world(torch.ones(4, device=dev))
+        else:
             if world % 2 != 0:
                 raise ValueError("shard mode needs an even number of ranks (2-way CFG split)")
             comm = TorchComm(lambda r: Layout(world, r, T))
@@ -209,11 +327,8 @@ def main():
             probe = torch.ones(4, device=dev, dtype=torch.float64)          # exercise the collectives once
             comm.all_reduce_sum(probe, pipe.parallel.lay.frame_group)
             comm.all_gather(probe, pipe.parallel.lay.pair_group)
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            pipe.parallel = None
-            mode, mode_note = "replicas", f" (shard mode unavailable: {type(e).__name__}: {e})"
-    inp = synthetic_inputs(dev, seed=42 + (rank if mode == "replicas" else 0))
+        torch.cuda.synchronize()
+    inp = config_inputs(dev, cfg, seed=42 + (rank if mode == "replicas" else 0))
 
     def barrier():
         torch.cuda.synchronize()
@@ -222,13 +337,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        run_clip(pipe, inp)
+        run_config(pipe, inp, cfg)
     timer = ops.LaunchTimer()
     ops.TIMER = timer
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        frames = run_clip(pipe, inp)
+        frames = run_config(pipe, inp, cfg)
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
@@ -269,29 +384,50 @@ def main():
             roofline["attn_spatial_kernel"] = dict(achieved=round(at["flops"] / at["seconds"] / 1e12, 1), unit="TFLOP/s",
                                                    frac=round(at["flops"] / at["seconds"] / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                                    share_of_clip_time=round(at["seconds"] / dt, 3))
+        # HBM-bound kernels of the adapter on REAL bytes (8 TB/s peak; MI355X_MICROARCH.md): the forward-splat warp
+        # (count / scan / fill / sort / gather, timed as one op; bytes = per flow frame and target pixel: C fp16 read + C fp16
+        # written + the flow + its CSR entries) and the full-resolution 16 / 32-channel condition-embedding convolutions (rows x
+        # (64 padded input channels + N output channels) x 2 B)
+        hbm = {}
+        ss = summ.get("softsplat_avg")
+        if ss and ss["seconds"] > 0:
+            hbm["softsplat_avg (ss_count/scan/fill/sort/gather)"] = dict(
+                achieved=round(ss["bytes"] / ss["seconds"] / 1e9, 1), peak=8000.0, unit="GB/s",
+                frac=round(ss["bytes"] / ss["seconds"] / 8e12, 4), launches=ss["launches"])
+        small = [(tag, v) for tag, v in timer.by_tag().items() if tag[4] <= 32 and tag[3] >= 100000]
+        if small:
+            by = sum(v[0] * tag[3] * (64 + tag[4]) * 2.0 for tag, v in small)
+            sec = sum(v[1] for tag, v in small)
+            hbm["igemm_f16_kernel, full-resolution 16/32-channel adapter convolutions"] = dict(
+                achieved=round(by / sec / 1e9, 1), peak=8000.0, unit="GB/s", frac=round(by / sec / 8e12, 4),
+                launches=sum(v[0] for _, v in small))
+        if hbm:
+            roofline["hbm_kernels"] = hbm
         clips = args.steps * (world if mode == "replicas" else 1)
-        value = T * clips / dt
+        nfr = LONG_FRAMES if cfg == 5 else T
+        value = nfr * clips / dt
         par_desc = {"single": "1 GPU", "replicas": f"{world} independent clips, one per GPU, no data-path collective",
-                    "shard": f"one clip over {world} GPUs: 2-way CFG x {max(world // 2, 1)}-way frame shards; RCCL "
-                             "all-reduce (temporal GroupNorm sums), halo p2p (temporal convs), all-gather (temporal "
-                             "attention K|V, CFG pair, final latents); VAE chunks round-robin"}[mode] + mode_note
+                    "shard": (f"one clip over {world} GPUs: the distinct windows of a step dealt round-robin to the ranks, one "
+                              "all-gather of the stepped window latents per round; VAE chunks round-robin" if cfg == 5 else
+                              f"one clip over {world} GPUs: 2-way CFG x {max(world // 2, 1)}-way frame shards; RCCL "
+                              "all-reduce (temporal GroupNorm sums), halo p2p (temporal convs), all-gather (temporal "
+                              "attention K|V, CFG pair, final latents); VAE chunks round-robin")}[mode]
         line = {
-            "metric": "denoised frames/sec, 25f 576x1024 SVD+MOFA, 25 steps", "value": round(value, 4),
+            "metric": ("denoised frames/sec, 25f 576x1024 SVD+MOFA, 25 steps" if cfg != 5 else
+                       "denoised frames/sec, 97f (4 x 25f windows) 576x1024 SVD+MOFA hybrid, 25 steps"), "value": round(value, 4),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "strong" if mode == "shard" else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "MOFA-Video-Traj, 25-frame 576x1024, 25 denoise steps + temporal VAE decode "
-                                   "(chunk 8), single trajectory hint, SVD-XT UNet + MOFA-Adapter, CFG 1->3, "
-                                   "seeded random weights in the reference checkpoint layout",
-                       "num_frames": T, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
+            "config": {"workload": WORKLOADS[cfg], "baseline_config_index": cfg - 1,
+                       "num_frames": nfr, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
                        "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
                        "output_finite": finite,
-                       "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOP * clips / dt / world, 1)},
+                       "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and cfg == 2:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if dist is not None:

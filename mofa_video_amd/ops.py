@@ -22,6 +22,7 @@ class LaunchTimer:
 
     def __init__(self):
         self.rec = []
+        self.tags = []
 
     def start(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -34,8 +35,6 @@ class LaunchTimer:
         self.rec.append((name, e0, e1, flops, nbytes))
         if tag is not None:
             self.tags.append((tag, len(self.rec) - 1))
-
-    tags = []
 
     def by_tag(self):
         torch.cuda.synchronize()
@@ -413,8 +412,11 @@ def softsplat_avg_tokens(feat, flow, H, W):
     Cc = feat.shape[1]
     ws = torch.empty((lib.mofa_softsplat_ws_bytes(nflows, H, W),), dtype=torch.uint8, device=feat.device)
     out = torch.empty((nflows * H * W, Cc), dtype=F16, device=feat.device)
+    t0 = TIMER.start() if TIMER is not None else None
     L.check(lib.mofa_softsplat_avg_f16(L.ptr(feat), L.ptr(flow.contiguous()), L.ptr(out), L.ptr(ws), nflows, H, W, Cc,
                                        _ld(feat), _ld(out), L.stream_ptr()), "mofa_softsplat_avg_f16")
+    if t0 is not None:       # real bytes per flow frame and pixel: C fp16 gathered + C fp16 written, the flow, <= 4 CSR entries
+        TIMER.stop("softsplat_avg", t0, nbytes=float(nflows) * H * W * (4.0 * Cc + 8.0 + 64.0))
     return out
 
 
