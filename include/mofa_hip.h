@@ -111,6 +111,12 @@ int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int ncb, int S, i
 int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out,
                            int nclips, int Tq, int T, int HW, int heads, int head_dim, int ld, int ldkv, int ldo,
                            float scale, mofa_stream_t stream);
+/* the same with a key-frame validity mask (bit j = key frame j exists).  Frame-sharded clips all-gather K|V into ONE
+ * buffer of ranks x (largest shard) frames; with uneven shards (25 frames over 4 ranks = 7/6/6/6) the padding frames of
+ * the shorter shards are masked here instead of being compacted away by a copy (rows of masked frames are never read). */
+int mofa_attn_temporal_masked_f16(const void* q, const void* k, const void* v, void* out,
+                                  int nclips, int Tq, int T, int HW, int heads, int head_dim, int ld, int ldkv, int ldo,
+                                  float scale, uint32_t key_mask, mofa_stream_t stream);
 /* in-place row softmax of an fp16 [rows][cols] matrix (VAE mid-block attention, 1 head x 512) */
 int mofa_softmax_rows_f16(void* x, int rows, int cols, int ld, mofa_stream_t stream);
 

@@ -267,6 +267,14 @@ class SelfAttn:
         Cc = self.C
         return qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
 
+    def kv_into(self, x, out):
+        """the K|V projection alone, written in place into ``out`` [rows, 2C] (a frame shard's slot of the all-gather
+        buffer)"""
+        return ops.igemm(x, self.wqkv[self.C:], out=out)
+
+    def q(self, x):
+        return ops.igemm(x, self.wqkv[:self.C])
+
 
 class TransformerSpatioTemporal:
     """diffusers TransformerSpatioTemporalModel (one spatial + one temporal transformer block)."""
@@ -313,17 +321,31 @@ class TransformerSpatioTemporal:
         # --- TemporalBasicTransformerBlock on h + pos[t] ---
         pos_rv = (HW, 1, 1, T)
         f = self.ff_in(self.norm_in(h, rowvec=pos, rv_div=HW, rv_mod=T), r1=h, s1=1.0, rowvec=pos, rv=pos_rv)
-        q, k, v = self.tattn1.qkv(self.tnorm1(f))
         if c.par is None:
+            q, k, v = self.tattn1.qkv(self.tnorm1(f))
             a = ops.attn_temporal(q, k, v, B, T, HW, self.heads, head_dim=self.tattn1.head_dim)
-        else:   # this rank holds T of the clip's T_full frames: all-gather K|V along the frame axis
-            Cc = self.C
-            kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
-            ops.copy2d(k, kv[:, :Cc])
-            ops.copy2d(v, kv[:, Cc:])
-            kv = c.par.gather_frames(kv, HW)
-            a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, c.par.T_full, HW, self.heads,
-                                  head_dim=self.tattn1.head_dim, Tq=T)
+        else:
+            # this rank holds T of the clip's T_full frames.  The K|V projection writes this shard's slot of the gather
+            # buffer, one all_gather_into_tensor (asynchronous, RCCL's stream) fills the other slots while the Q
+            # projection runs, and the attention kernel masks the padding frames of the shorter shards.
+            Cc, par = self.C, c.par
+            fn = self.tnorm1(f)
+            if par.kv_slots <= 32:
+                kv, own = par.kv_buffer(HW, 2 * Cc, fn.device)
+                self.tattn1.kv_into(fn, own)
+                work = par.kv_gather_begin(kv, HW)
+                q = self.tattn1.q(fn)
+                work.wait()
+                a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.kv_slots, HW, self.heads,
+                                      head_dim=self.tattn1.head_dim, Tq=T, key_mask=par.kv_mask)
+            else:   # more than 32 key slots after padding (e.g. 31 frames over 3 shards): compact to T_full frames
+                q, k, v = self.tattn1.qkv(fn)
+                kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
+                ops.copy2d(k, kv[:, :Cc])
+                ops.copy2d(v, kv[:, Cc:])
+                kv = par.gather_frames(kv, HW)
+                a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.T_full, HW, self.heads,
+                                      head_dim=self.tattn1.head_dim, Tq=T)
         # temporal cross-attention row vector.  diffusers 0.24.0 quirk: token row (b, s) of the GLOBAL batch takes the
         # context of batch (b*HW + s) mod B_global; v_tm has one row per global batch element.
         Bg = v_tm.shape[0]

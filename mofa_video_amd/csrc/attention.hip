@@ -292,9 +292,10 @@ template <int D, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                  const f16* __restrict__ v, f16* __restrict__ out,
                                                                  long long nseq, int Tq, int T, int HW, int heads, int ld,
-                                                                 int ldkv, int ldo, float scale) {
+                                                                 int ldkv, int ldo, float scale, unsigned key_mask) {
     // Tq query frames (rows of q/out, clip stride Tq*HW), T key/value frames (rows of k/v, clip stride T*HW):
-    // Tq < T when the clip's frames are sharded over ranks and K/V were all-gathered.
+    // Tq < T when the clip's frames are sharded over ranks and K/V were all-gathered.  key_mask: bit j clear = key frame j
+    // does not exist (padding rows of uneven frame shards in the gathered buffer: never read, weight exactly 0).
     constexpr int DC = D / 8;       // 16-byte chunks per row
     constexpr int DH = D / 2;       // output dims per lane half
     __shared__ __attribute__((aligned(16))) f16 sK[WPB][32 * D];
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
         qbase = ((size_t)b * Tq * HW + p);  // q/out token row of frame 0
         for (int c = lane; c < T * DC; c += 64) {
             const int t = c / DC, cc = c - t * DC;
+            if (!((key_mask >> t) & 1u)) continue;
             const size_t row = base + (size_t)t * HW;
             *(f16x8*)&sK[wave][t * D + cc * 8] = *(const f16x8*)(k + row * ldkv + head * D + cc * 8);
             *(f16x8*)&sV[wave][t * D + cc * 8] = *(const f16x8*)(v + row * ldkv + head * D + cc * 8);
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
     for (int jj = 0; jj < 16; ++jj) {
         const int j = hf * 16 + jj;
         float acc = 0.f;
-        if (j < T) {
+        if (j < T && ((key_mask >> j) & 1u)) {
             const f16* kp = &sK[wave][j * D];
 #pragma unroll
             for (int cidx = 0; cidx < DC; ++cidx) {
@@ -374,7 +376,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
         const float other = __shfl_xor(sc[jj], 32, 64);
         const float p_lo = hf == 0 ? sc[jj] : other;   // key jj
         const float p_hi = hf == 0 ? other : sc[jj];   // key 16 + jj
-        if (jj < T) {
+        if (jj < T && ((key_mask >> jj) & 1u)) {
             const f16* vp = &sV[wave][jj * D + hf * DH];
 #pragma unroll
             for (int cidx = 0; cidx < DH / 8; ++cidx) {
@@ -383,7 +385,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
                 for (int e = 0; e < 8; ++e) ov[cidx * 8 + e] = fmaf(p_lo, (float)a[e], ov[cidx * 8 + e]);
             }
         }
-        if (16 + jj < T) {
+        if (16 + jj < T && ((key_mask >> (16 + jj)) & 1u)) {
             const f16* vp = &sV[wave][(16 + jj) * D + hf * DH];
 #pragma unroll
             for (int cidx = 0; cidx < DH / 8; ++cidx) {
@@ -405,24 +407,35 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
     }
 }
 
-extern "C" int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out, int nclips, int Tq, int T,
-                                      int HW, int heads, int head_dim, int ld, int ldkv, int ldo, float scale,
-                                      mofa_stream_t stream) {
+extern "C" int mofa_attn_temporal_masked_f16(const void* q, const void* k, const void* v, void* out, int nclips, int Tq,
+                                             int T, int HW, int heads, int head_dim, int ld, int ldkv, int ldo, float scale,
+                                             uint32_t key_mask, mofa_stream_t stream) {
     if (!q || !k || !v || !out || nclips <= 0 || T <= 0 || T > 32 || Tq <= 0 || Tq > T || HW <= 0 || heads <= 0)
         return MOFA_EINVAL;
+    if (T < 32) key_mask &= (1u << T) - 1u;
+    if (key_mask == 0) return MOFA_EINVAL;
     if (ld % 8 != 0 || ldkv % 8 != 0 || ldo % 8 != 0) return MOFA_EINVAL;
     const long long nseq = (long long)nclips * HW * heads;
     if (head_dim == 64) {
         hipLaunchKernelGGL((attn_temporal_kernel<64, 4>), dim3(cdiv(nseq, 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, Tq, T, HW, heads, ld, ldkv, ldo, scale);
+                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, Tq, T, HW, heads, ld, ldkv, ldo, scale,
+                           key_mask);
     } else if (head_dim == 128) {
         hipLaunchKernelGGL((attn_temporal_kernel<128, 2>), dim3(cdiv(nseq, 2)), dim3(128), 0, (hipStream_t)stream,
-                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, Tq, T, HW, heads, ld, ldkv, ldo, scale);
+                           (const f16*)q, (const f16*)k, (const f16*)v, (f16*)out, nseq, Tq, T, HW, heads, ld, ldkv, ldo, scale,
+                           key_mask);
     } else {
         return MOFA_EINVAL;
     }
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
+}
+
+extern "C" int mofa_attn_temporal_f16(const void* q, const void* k, const void* v, void* out, int nclips, int Tq, int T,
+                                      int HW, int heads, int head_dim, int ld, int ldkv, int ldo, float scale,
+                                      mofa_stream_t stream) {
+    return mofa_attn_temporal_masked_f16(q, k, v, out, nclips, Tq, T, HW, heads, head_dim, ld, ldkv, ldo, scale, 0xffffffffu,
+                                         stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_attn_temporal_masked_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint32, _P],
     "mofa_softmax_rows_f16": [_P, _I, _I, _I, _P],
     "mofa_gn_nparts": [_I, _I],
     "mofa_gn_partial_f16": [_P, _P, _I, _I, _I, _I, _P],

@@ -228,16 +228,22 @@ def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None):
     return out
 
 
-def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=None, Tq=None):
-    """k/v hold T frames per clip; q holds Tq <= T (Tq < T: frame-sharded clip with all-gathered K/V)."""
+def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=None, Tq=None, key_mask=None):
+    """k/v hold T frames per clip; q holds Tq <= T (Tq < T: frame-sharded clip with all-gathered K/V).  key_mask: bit j =
+    key frame j exists (padding frames of uneven shards in the gathered buffer are masked, never read)."""
     lib = L.load()
     assert _ld(k) == _ld(v)
     Tq = T if Tq is None else Tq
     scale = head_dim ** -0.5 if scale is None else scale
     if out is None:
         out = torch.empty((nclips * Tq * HW, heads * head_dim), dtype=F16, device=q.device)
-    L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, Tq, T, HW, heads, head_dim,
-                                       _ld(q), _ld(k), _ld(out), scale, L.stream_ptr()), "mofa_attn_temporal_f16")
+    if key_mask is None:
+        L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, Tq, T, HW, heads, head_dim,
+                                           _ld(q), _ld(k), _ld(out), scale, L.stream_ptr()), "mofa_attn_temporal_f16")
+    else:
+        L.check(lib.mofa_attn_temporal_masked_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, Tq, T, HW, heads, head_dim,
+                                                  _ld(q), _ld(k), _ld(out), scale, int(key_mask), L.stream_ptr()),
+                "mofa_attn_temporal_masked_f16")
     return out
 
 

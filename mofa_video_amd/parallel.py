@@ -6,7 +6,10 @@ Layout for N ranks (N in 1, 2, 4, 8, ...):  2-way CFG x (N/2)-way frames.
 Weights are replicated.  Exchanges inside one denoise step (RCCL over xGMI through torch.distributed):
     * temporal GroupNorm (statistics span all T frames): all-reduce of fp64 [32][2] partial sums   (frame group)
     * temporal (3,1,1) convolution: one halo frame from each neighbour shard (batched p2p)        (frame group)
-    * temporal self-attention: all-gather of the K|V token columns along the frame axis            (frame group)
+    * temporal self-attention: ONE all_gather_into_tensor of the K|V token columns into a preallocated
+      [frame_ranks x T_max frames] buffer (the K|V projection writes this rank's slot in place, the collective runs
+      asynchronously under the Q projection, and the attention kernel masks the padding frames of uneven shards --
+      no pad / concat / compaction copies)                                                          (frame group)
     * CFG combine: the two halves of one frame shard swap their noise predictions                 (pair group)
 and once per clip: all-gather of the final latents before the VAE decode, whose chunks are independent and are
 dealt round-robin to ALL ranks.  Everything per-frame (2-D convs, spatial norms/attention, FFs, the adapter warps,
@@ -33,10 +36,15 @@ def split_frames(T, n):
 
 
 class Layout:
-    def __init__(self, world, rank, T):
-        assert world >= 1 and (world == 1 or world % 2 == 0), "1 or an even number of ranks"
+    def __init__(self, world, rank, T, cfg_ranks=None):
+        """cfg_ranks: None = 2 whenever world >= 2 (the product layout).  1 = frames only (both CFG halves on every
+        rank) -- used by the exchange-primitive tests to shard frames over 2 ranks; the pipelines use the default."""
+        if cfg_ranks is None:
+            assert world >= 1 and (world == 1 or world % 2 == 0), "1 or an even number of ranks"
+            cfg_ranks = 2 if world >= 2 else 1
+        assert cfg_ranks in (1, 2) and world % cfg_ranks == 0
         self.world, self.rank, self.T = world, rank, T
-        self.cfg_ranks = 2 if world >= 2 else 1
+        self.cfg_ranks = cfg_ranks
         self.frame_ranks = world // self.cfg_ranks
         assert self.frame_ranks <= T
         self.half = rank // self.frame_ranks if self.cfg_ranks == 2 else None
@@ -97,9 +105,20 @@ class TorchComm:
         n = self.dist.get_world_size()
         if n == 1:
             return [t]
-        outs = [torch.empty_like(t) for _ in range(n)]
-        self.dist.all_gather(outs, t.contiguous())
-        return outs
+        t = t.contiguous()
+        flat = torch.empty((n * t.numel(),), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(flat, t.reshape(-1))
+        return list(flat.reshape((n,) + tuple(t.shape)).unbind(0))
+
+    def all_gather_into(self, buf, slot_rows, ranks):
+        """In-place all-gather: ``buf`` [len(ranks) * slot_rows, C] already holds this rank's rows in its own slot; after
+        ``wait()`` it holds every rank's.  Asynchronous: RCCL runs the collective on its own stream, kernels launched
+        between this call and ``wait()`` overlap it (``wait`` makes the CURRENT stream wait, the host does not block)."""
+        if len(ranks) == 1:
+            return _Done()
+        i = list(ranks).index(self.rank)
+        return self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=self._g(ranks),
+                                                async_op=True)
 
     def exchange_halo(self, first, last, prev_rank, next_rank):
         """send `first` to prev and `last` to next; receive prev's last and next's first (None at the clip ends)"""
@@ -115,6 +134,11 @@ class TorchComm:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
         return from_prev, from_next
+
+
+class _Done:
+    def wait(self):
+        return True
 
 
 class ThreadWorld:
@@ -165,6 +189,20 @@ class ThreadComm:
     def all_gather_world(self, t):
         return self.all_gather(t, list(range(self.tw.world)))
 
+    def all_gather_into(self, buf, slot_rows, ranks):
+        if len(ranks) == 1:
+            return _Done()
+        i = list(ranks).index(self.rank)
+        got = self._exchange(buf[i * slot_rows:(i + 1) * slot_rows], ranks)
+        for j, g in enumerate(got):
+            if j != i:
+                buf[j * slot_rows:(j + 1) * slot_rows].copy_(g)
+        if buf.is_cuda:
+            torch.cuda.current_stream().synchronize()      # the peers' slots must stay put until they were read
+        bar, _ = self.tw._group_state(ranks)
+        bar.wait()
+        return _Done()
+
 
 # ---------------------------------------------------------------------------------------------------------
 class FrameParallel:
@@ -206,6 +244,30 @@ class FrameParallel:
         return ext
 
     # temporal attention K/V ---------------------------------------------------------------------------------
+    @property
+    def kv_slots(self):
+        """key-frame slots of the gathered K|V buffer (frame_ranks x largest shard); the masked attention entry takes
+        at most 32"""
+        return self.lay.frame_ranks * self.lay.T_max
+
+    @property
+    def kv_mask(self):
+        """bit (shard * T_max + t) set for the frames shard holds: the padding frames of the shorter shards are clear"""
+        m = 0
+        for s_, (a, b) in enumerate(self.lay.bounds):
+            m |= ((1 << (b - a)) - 1) << (s_ * self.lay.T_max)
+        return m
+
+    def kv_buffer(self, rows_per_frame, C2, device):
+        """-> (buf [kv_slots * rows, C2] uninitialised, own [T_loc * rows, C2] = this rank's slot of it)"""
+        lay = self.lay
+        slot = lay.T_max * rows_per_frame
+        buf = torch.empty((lay.frame_ranks * slot, C2), dtype=torch.float16, device=device)
+        return buf, buf[lay.shard * slot:lay.shard * slot + self.T_loc * rows_per_frame]
+
+    def kv_gather_begin(self, buf, rows_per_frame):
+        return self.comm.all_gather_into(buf, self.lay.T_max * rows_per_frame, self.lay.frame_group)
+
     def gather_frames(self, t, rows_per_frame):
         """t [T_loc*rows, C] (this shard's frames) -> [T_full*rows, C] in frame order (uneven shards are padded to
         the largest for the collective and compacted afterwards)."""

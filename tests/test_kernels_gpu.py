@@ -399,6 +399,32 @@ def test_attn_temporal_sharded_queries(ops):
     assert torch.equal(part, full[f0 * HW:(f0 + Tq) * HW])
 
 
+@pytest.mark.parametrize("T,R,hd", [(25, 4, 64), (25, 2, 64), (7, 2, 128), (5, 4, 64), (32, 4, 64)])
+def test_attn_temporal_masked_padded_shards(ops, T, R, hd):
+    """K|V laid out as the frame-sharded all-gather leaves them: R slots of T_max frames, the shorter shards' padding
+    frames holding NaN (never-written memory); with the key mask the result equals attention over the T real frames"""
+    from mofa_video_amd.parallel import split_frames
+    HW, heads = 11, 2
+    Cc = heads * hd
+    qkv = _h(T * HW, 3 * Cc, seed=64)
+    d = qkv.to(DEV)
+    full = ops.attn_temporal(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], 1, T, HW, heads, head_dim=hd)
+    bounds = split_frames(T, R)
+    T_max = bounds[0][1] - bounds[0][0]
+    pad = torch.full((R * T_max * HW, 2 * Cc), float("nan"), dtype=torch.float16, device=DEV)
+    mask = 0
+    for s_, (a, b) in enumerate(bounds):
+        pad[s_ * T_max * HW:(s_ * T_max + b - a) * HW] = d[a * HW:b * HW, Cc:]
+        mask |= ((1 << (b - a)) - 1) << (s_ * T_max)
+    for (a, b) in bounds:                                           # every shard's queries against the padded buffer
+        part = ops.attn_temporal(d[a * HW:b * HW, :Cc], pad[:, :Cc], pad[:, Cc:], 1, R * T_max, HW, heads, head_dim=hd,
+                                 Tq=b - a, key_mask=mask)
+        assert torch.isfinite(part).all()
+        _close(part, full[a * HW:b * HW].float().cpu(), tol=1e-3, what="masked temporal attention")
+    with pytest.raises(Exception):                                  # an all-zero mask is an argument error, not a NaN
+        ops.attn_temporal(d[:HW, :Cc], pad[:, :Cc], pad[:, Cc:], 1, R * T_max, HW, heads, head_dim=hd, Tq=1, key_mask=0)
+
+
 @pytest.mark.parametrize("N,kinds", [(64, ("r1",)), (64, ("r1", "rv")), (64, ("bias", "r1", "r2", "rv")), (256, ("r1",)),
                                      (256, ("bias",)), (128, ("bias", "r1"))])
 def test_igemm_repeat_launches_bit_identical(ops, N, kinds):

@@ -78,6 +78,26 @@ def _worker(rank, world, port, T, HW, C):
         lat = par.gather_frames(mine.reshape(lay.T_loc, HW * C), 1)
         assert torch.equal(lat, full[h].reshape(T, HW * C))
 
+        # 3b. the in-place K|V all-gather of the temporal attention: this shard's rows are written into its own slot of a
+        #     [frame_ranks x T_max frames] buffer, ONE all_gather_into_tensor fills the rest, the padding frames of the
+        #     shorter shards stay untouched and are excluded by the key mask
+        buf, own = par.kv_buffer(HW, C, mine.device)
+        assert own.shape == mine.shape and par.kv_slots == lay.frame_ranks * lay.T_max
+        buf.fill_(float("nan"))
+        own.copy_(mine.half())
+        par.kv_gather_begin(buf, HW).wait()
+        mask = par.kv_mask
+        assert bin(mask).count("1") == T
+        for s_, (a, b) in enumerate(lay.bounds):
+            for t in range(lay.T_max):
+                slot = buf[(s_ * lay.T_max + t) * HW:(s_ * lay.T_max + t + 1) * HW]
+                if t < b - a:
+                    assert (mask >> (s_ * lay.T_max + t)) & 1
+                    assert torch.equal(slot, full[h, (a + t) * HW:(a + t + 1) * HW].half()), (rank, s_, t)
+                else:
+                    assert not (mask >> (s_ * lay.T_max + t)) & 1
+                    assert torch.isnan(slot).all()                      # padding frames: never written
+
         # 4. CFG pair exchange: unconditional half first
         if world >= 2:
             both = par.gather_cfg(mine[:, :4].contiguous())
@@ -114,6 +134,22 @@ def _window_worker(rank, world, port, nwin):
             assert torch.equal(v, torch.full((4, 3), float(k[0])))
     finally:
         dist.destroy_process_group()
+
+
+def _frames_only_worker(rank, world, port, T, HW, C):
+    """cfg_ranks = 1: the frames of BOTH halves sharded over 2 ranks (the layout the 2-GPU nccl test also uses)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from frame_exchange_checks import check_frame_exchanges
+        check_frame_exchanges(rank, world, T, HW, C, "cpu")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T", [4, 5])
+def test_frames_only_layout_gloo(T):
+    mp.spawn(_frames_only_worker, args=(2, _free_port(), T, 6, 32), nprocs=2, join=True)
 
 
 @pytest.mark.parametrize("world,nwin", [(2, 3), (2, 4), (4, 3)])

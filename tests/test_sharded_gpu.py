@@ -18,6 +18,10 @@ T, H, W, STEPS = 4, 256, 256, 2
 
 @pytest.fixture(scope="module")
 def setup():
+    return build_run(DEV)
+
+
+def build_run(DEV):
     from mofa_video_amd import schema
     from mofa_video_amd.adapter import FlowControlNet
     from mofa_video_amd.pipeline import FlowControlNetPipeline
@@ -30,19 +34,22 @@ def setup():
     hu = UNetSpatioTemporalConditionControlNetModel(sdu, TINY, DEV)
     hc = FlowControlNet(sdc, TINY_CN, DEV)
     hv = AutoencoderKLTemporalDecoder(sdv, TINY_VAE, DEV)
-    inp = synthetic_inputs(T, H, W, cross_dim=TINY["cross_attention_dim"])
+    inputs = {}
 
-    def run(parallel=None, output_type="latent"):
+    def run(parallel=None, output_type="latent", frames=T):
+        if frames not in inputs:
+            inputs[frames] = synthetic_inputs(frames, H, W, cross_dim=TINY["cross_attention_dim"])
+        inp = inputs[frames]
         pipe = FlowControlNetPipeline(vae=hv, unet=hu, controlnet=hc, scheduler=EulerDiscreteScheduler(),
                                       parallel=parallel)
         return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=H, width=W,
-                    num_frames=T, num_inference_steps=STEPS, decode_chunk_size=2, latents=inp["latents"],
+                    num_frames=frames, num_inference_steps=STEPS, decode_chunk_size=2, latents=inp["latents"],
                     output_type=output_type, image_embeddings=inp["image_embeddings"],
                     image_latents=inp["image_latents"]).frames
     return run
 
 
-def _run_virtual_ranks(run, world, output_type="latent"):
+def _run_virtual_ranks(run, world, output_type="latent", T=T):
     from mofa_video_amd.parallel import FrameParallel, Layout, ThreadComm, ThreadWorld
     tw = ThreadWorld(world)
     results, errors = [None] * world, []
@@ -51,7 +58,7 @@ def _run_virtual_ranks(run, world, output_type="latent"):
         try:
             torch.cuda.set_device(0)
             par = FrameParallel(Layout(world, r, T), ThreadComm(tw, r))
-            results[r] = run(par, output_type)
+            results[r] = run(par, output_type, T)
         except Exception as e:  # noqa: BLE001
             errors.append((r, repr(e)))
             for b in tw.barriers.values():
@@ -73,6 +80,20 @@ def test_sharded_latents_equal_single_rank(setup, world):
     for r, o in enumerate(outs):
         e = rel_l2(o, ref)
         print(f"world {world} rank {r}: latents rel-L2 vs single rank {e:.3e}")
+        assert tuple(o.shape) == tuple(ref.shape)
+        assert e < 2e-3, (world, r, e)
+
+
+@pytest.mark.parametrize("world,frames", [(4, 5), (8, 7)])
+def test_uneven_frame_shards_equal_single_rank(setup, world, frames):
+    """5 frames over 2 shards (3 + 2), 7 over 4 (2 + 2 + 2 + 1): the gathered K|V buffer has padding frames the temporal
+    attention masks; halo frames and GroupNorm partials come from shards of different length"""
+    run = setup
+    ref = run(None, "latent", frames)
+    outs = _run_virtual_ranks(run, world, T=frames)
+    for r, o in enumerate(outs):
+        e = rel_l2(o, ref)
+        print(f"world {world}, {frames} frames, rank {r}: latents rel-L2 vs single rank {e:.3e}")
         assert tuple(o.shape) == tuple(ref.shape)
         assert e < 2e-3, (world, r, e)
 
