@@ -320,12 +320,24 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
     // kinds without residuals (plain, row vector, GEGLU): bias / row vector / activation in the accumulator (fragment)
     // layout -- register r of accumulator tile (i, j) is row 32 i + l31, column 32 j + 8 (r >> 2) + 4 lh + (r & 3) --
     // then fp16 and a 32 x 64 fp16 transpose through the scratch; a lane stores 8 consecutive columns of one row
-    auto epilogue_light = [&](auto ac, f32x16 (&acc)[MI][NJ], const int mw, const int nw) __attribute__((always_inline)) {
+    // UNI (row-vector kinds): every row of the wave's 128 x 64 block takes the SAME row of the row-vector table (time
+    // embedding per frame / cross-attention vector per clip: true for every tile that does not straddle a frame), so its 64
+    // values are loaded ONCE per tile.  Per-row loads in the fragment layout are 16 load instructions per 32-row block and
+    // wave, 16 bytes per lane each: 8 waves x 4 blocks of them keep the CU's one texture path busy for >= 8 000 cycles per
+    // tile, which is what the row-vector epilogue cost (15-19 k cycles against 5 k for the plain one).
+    auto epilogue_light = [&](auto ac, auto un, f32x16 (&acc)[MI][NJ], const int mw, const int nw, const int idx_u) __attribute__((always_inline)) {
+        constexpr bool UNI = decltype(un)::v != 0;
+        // lane-derived LDS / global offsets are recomputed per tile from a laundered lane id: hoisted out of the tile loop
+        // they stay live across the K loop and get spilled to scratch (and reloaded here, latency-bound)
+        // (row-vector kinds only, the ones that spilled: elsewhere the hoisted offsets fit and recomputing them costs 500-900
+        // cycles per tile)
+        const int lane_e = RV ? lane_now() : lane;
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
         f16* out = (f16*)a.out;
         float saccv = a.s_acc;                                     // VGPR operand on purpose (see igemm.hip's epilogue)
         asm volatile("" : "+v"(saccv));
-        f32x4 bv[NJ][4];
-        if (!RV) {
+        f32x4 bv[NJ][4];                                           // bias (from the scratch); UNI: bias + row vector
+        if (!RV || UNI) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -334,13 +346,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
         const int nout = GEGLU ? a.N / 2 : a.N;
         int rv_div = a.rv_div, rv_mod_in = a.rv_mod_in, rv_mod_out = a.rv_mod_out;
         asm volatile("" : "+s"(rv_div), "+s"(rv_mod_in), "+s"(rv_mod_out));   // reciprocals are set up here, not hoisted
-        // row-vector values of accumulator row block i: block i + 1's are loaded as soon as block i's arithmetic is
-        // done (same registers), so the load latency hides behind block i's transpose and stores
+        // not UNI: row-vector values of accumulator row block i; block i + 1's are loaded as soon as block i's arithmetic
+        // is done (same registers), so the load latency hides behind block i's transpose and stores
         f32x4 rv[NJ][4];
         auto rv_load = [&](int i, f32x4 (&rv)[NJ][4]) __attribute__((always_inline)) {
             int m = mw + 32 * i + l31;
             m = m < a.M ? m : a.M - 1;
-            const int idx = ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
+            const int idx = UNI ? idx_u : ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
             const float* rvp = a.rowvec + (size_t)idx * a.N;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
@@ -349,10 +361,16 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
                     int n = nw + 32 * j + 8 * g + 4 * lh;
                     n = n + 4 <= a.N ? n : 0;                       // columns beyond N are never stored
                     rv[j][g] = *(const f32x4*)(rvp + n);
-                    if (a.bias) rv[j][g] += *(const f32x4*)(a.bias + n);   // (row-vector kinds: bias rides along, L1-hot)
+                    if (!UNI && a.bias) rv[j][g] += *(const f32x4*)(a.bias + n);   // (per-row path: the bias rides along)
                 }
         };
         if (RV) rv_load(0, rv);
+        if (RV && UNI) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[j][g] += rv[j][g];
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             if constexpr (GEGLU) {
@@ -387,12 +405,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
                         f16x4 o;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float v = acc[i][j][4 * g + e] + (RV ? rv[j][g][e] : bv[j][g][e]);
+                            const float v = acc[i][j][4 * g + e] + (RV && !UNI ? rv[j][g][e] : bv[j][g][e]);
                             o[e] = (f16)act_apply(ac, saccv * v);
                         }
                         *(f16x4*)(scr + h16_off(l31, 8 * j + 2 * g + lh)) = o;
                     }
-                if (RV && i + 1 < MI) rv_load(i + 1, rv);
+                if (RV && !UNI && i + 1 < MI) rv_load(i + 1, rv);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
                     const int row = 8 * p + (lane >> 3), blk = lane & 7;
@@ -408,10 +426,14 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
     // kinds with residuals: fp32 transpose, 32 x 32 per step (8 steps: accumulator tiles (i, j)); a lane owns 8 consecutive
     // columns of one row.  The residual / row-vector loads of step s + D are issued before step s is processed (a ring of
     // D steps in registers; D from the registers a step's loads take), so their latency hides behind D steps of work.
-    auto epilogue_residual = [&](f32x16 (&acc)[MI][NJ], const int mw, const int nw) __attribute__((always_inline)) {
+    auto epilogue_residual = [&](auto un, f32x16 (&acc)[MI][NJ], const int mw, const int nw, const int idx_u) __attribute__((always_inline)) {
+        constexpr bool UNI = decltype(un)::v != 0;                 // one row-vector row for the whole wave block (see above)
         constexpr int STEPS = MI * NJ;
-        constexpr int REGS = (R1 ? 8 : 0) + (R2 ? 8 : 0) + (RV ? 16 : 0);     // VGPRs of one step's loads
-        constexpr int D = REGS <= 8 ? 8 : (REGS <= 16 ? 4 : (REGS <= 24 ? 2 : 1));
+        constexpr int REGS = (R1 ? 8 : 0) + (R2 ? 8 : 0) + (RV && !UNI ? 16 : 0);   // VGPRs of one step's loads
+        constexpr int D0 = REGS <= 8 ? 8 : (REGS <= 16 ? 4 : (REGS <= 24 ? 2 : 1));
+        constexpr int D = RV && UNI ? (REGS <= 8 ? 4 : 2) : (RV ? 1 : D0);   // (row-vector kinds: 16 more registers are taken)
+        const int lane_e = RV ? lane_now() : lane;                 // (recomputed per tile, see epilogue_light)
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
         f16* out = (f16*)a.out;
         const f16* r1 = (const f16*)a.r1;
         const f16* r2 = (const f16*)a.r2;
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
                 m = m < a.M ? m : a.M - 1;
                 if (R1) l.t1[p] = *(const f16x8*)(r1 + (size_t)m * a.ldr1 + nc);
                 if (R2) l.t2[p] = *(const f16x8*)(r2 + (size_t)m * a.ldr2 + nc);
-                if (RV) {
+                if (RV && !UNI) {
                     const int idx = ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
                     const float* q = a.rowvec + (size_t)idx * a.N + nc;
                     l.rv0[p] = *(const f32x4*)q;
@@ -440,6 +462,16 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
                 }
             }
         };
+        f32x4 rvu[NJ][2];                                          // UNI: the row vector of this lane's 8 columns
+        if (RV && UNI) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = nw + 32 * j + 8 * piece;
+                const float* q = a.rowvec + (size_t)idx_u * a.N + (n + 8 <= a.N ? n : 0);
+                rvu[j][0] = *(const f32x4*)q;
+                rvu[j][1] = *(const f32x4*)(q + 4);
+            }
+        }
 #pragma unroll
         for (int st = 0; st < D && st < STEPS; ++st) step_loads(st, L[st]);
         f32x4 bv[NJ][2];                                           // bias of this lane's 8 columns, from the scratch
@@ -447,6 +479,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
         for (int j = 0; j < NJ; ++j) {
             bv[j][0] = *(const f32x4*)(scr + (32 * j + 8 * piece) * 4);
             bv[j][1] = *(const f32x4*)(scr + (32 * j + 8 * piece + 4) * 4);
+            if (RV && UNI) { bv[j][0] += rvu[j][0]; bv[j][1] += rvu[j][1]; }
         }
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
@@ -469,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x0 = v0[e] + bv[j][0][e], x1 = v1[e] + bv[j][1][e];
-                    if (RV) { x0 += l.rv0[p][e]; x1 += l.rv1[p][e]; }
+                    if (RV && !UNI) { x0 += l.rv0[p][e]; x1 += l.rv1[p][e]; }
                     x0 *= saccv; x1 *= saccv;
                     if (R1) { x0 += s1v * (float)l.t1[p][e]; x1 += s1v * (float)l.t1[p][4 + e]; }
                     if (R2) { x0 += s2v * (float)l.t2[p][e]; x1 += s2v * (float)l.t2[p][4 + e]; }
@@ -509,15 +542,39 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
         // ---- epilogue (no barriers; private scratch) ------------------------------------------------------------------
         const int mw = tm * TBM + wm * MI * 32;                    // first output row / (pre-GEGLU) column of this wave
         const int nw = tn * TBN + wn * NJ * 32;
+        int idx_u = -1;                                            // >= 0: the one row-vector row of this wave's block
+        if constexpr (RV) {
+            if (a.rv_mod_in == 1) {                                // idx(m) = ((m / div) * mul) % mod_out: a step function
+                int rv_div = a.rv_div;
+                asm volatile("" : "+s"(rv_div));
+                const int m0 = mw < a.M ? mw : a.M - 1, m1 = mw + 32 * MI - 1 < a.M ? mw + 32 * MI - 1 : a.M - 1;
+                const int q0 = m0 / rv_div, q1 = m1 / rv_div;
+                if (q0 == q1) idx_u = (q0 * a.rv_mul) % a.rv_mod_out;
+            }
+            idx_u = __builtin_amdgcn_readfirstlane(idx_u);
+        }
         if constexpr (R1 || R2) {
-            epilogue_residual(acc, mw, nw);
+            if (RV && idx_u >= 0) epilogue_residual(IC<1>{}, acc, mw, nw, idx_u);
+            else epilogue_residual(IC<0>{}, acc, mw, nw, 0);
         } else if constexpr (GEGLU) {
-            epilogue_light(IC<MOFA_ACT_NONE>{}, acc, mw, nw);
-        } else {                                                   // uniform dispatch: the activation is compiled in
-            if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, acc, mw, nw);
-            else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, acc, mw, nw);
-            else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, acc, mw, nw);
-            else epilogue_light(IC<MOFA_ACT_GELU>{}, acc, mw, nw);
+            epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
+        } else if constexpr (RV) {                                 // uniform dispatch: activation and UNI are compiled in
+            if (idx_u >= 0) {
+                if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<1>{}, acc, mw, nw, idx_u);
+                else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<1>{}, acc, mw, nw, idx_u);
+                else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<1>{}, acc, mw, nw, idx_u);
+                else epilogue_light(IC<MOFA_ACT_GELU>{}, IC<1>{}, acc, mw, nw, idx_u);
+            } else {
+                if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
+                else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<0>{}, acc, mw, nw, 0);
+                else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<0>{}, acc, mw, nw, 0);
+                else epilogue_light(IC<MOFA_ACT_GELU>{}, IC<0>{}, acc, mw, nw, 0);
+            }
+        } else {
+            if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
+            else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<0>{}, acc, mw, nw, 0);
+            else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<0>{}, acc, mw, nw, 0);
+            else epilogue_light(IC<MOFA_ACT_GELU>{}, IC<0>{}, acc, mw, nw, 0);
         }
         if (VAR & 64) { stamp(7); tr[8] += 1; }                   // epilogue (stores still in flight); tiles
     }

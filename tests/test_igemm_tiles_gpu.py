@@ -14,7 +14,10 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 TILES = {"128x128": 2, "192x128": 4, "256x256": 5}
-KINDS = ["bias", "r1", "r1r2", "rv", "r1rv", "r1r2rv", "silu", "gelu"]
+# "rvu": a row vector that is constant over blocks of 1000 rows (idx = ((m / 1000) * 3) % 5) -- the time-embedding / per-clip
+# pattern: waves whose 128 rows lie inside one block take the load-once path of the 256x256 kernel, waves that straddle a
+# block boundary the per-row path, both in the same launch; plain "rv" (idx = ((m / 7) * 3 + m % 4) % 5) changes every row
+KINDS = ["bias", "r1", "r1r2", "rv", "r1rv", "r1r2rv", "silu", "gelu", "rvu", "r1rvu", "r2rvu", "r1r2rvu", "rvusilu"]
 
 
 def _close(out, ref, tol=2e-3, what=""):
@@ -53,7 +56,8 @@ def _epilogue(kind, M, N, seed=100):
     bias = _f(N, seed=seed)
     kw, s_acc = dict(), 0.75
     r1 = r2 = rowvec = None
-    rv = (7, 3, 4, 5)                                   # idx = ((m / 7) * 3 + m % 4) % 5
+    uni = "rvu" in kind
+    rv = (1000, 3, 1, 5) if uni else (7, 3, 4, 5)       # idx = ((m / 1000) * 3) % 5  /  ((m / 7) * 3 + m % 4) % 5
     if "r1" in kind:
         r1 = _h(M, N, seed=seed + 1)
         kw.update(r1=r1, s1=0.5)
@@ -63,14 +67,14 @@ def _epilogue(kind, M, N, seed=100):
     if "rv" in kind:
         rowvec = _f(5, N, seed=seed + 3)
         kw.update(rowvec=rowvec, rv=rv)
-    act = {"silu": 1, "gelu": 4}.get(kind, 0)
+    act = 1 if kind.endswith("silu") else (4 if kind == "gelu" else 0)
     kw.update(act=act, s_acc=s_acc)
 
     def apply(acc):
         y = acc + bias
         if rowvec is not None:
             m = torch.arange(M, device=DEV)
-            y = y + rowvec[((m // 7) * 3 + m % 4) % 5]
+            y = y + rowvec[((m // 1000) * 3) % 5 if uni else ((m // 7) * 3 + m % 4) % 5]
         y = s_acc * y
         if r1 is not None:
             y = y + 0.5 * r1.float()
