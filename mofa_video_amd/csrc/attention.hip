@@ -16,6 +16,7 @@
 
 #define ATT_VSTR 68   // V^T tile row stride (halves): 136 B, conflict-free ds_read_b64
 #define ATT_TILE 64
+#define ATT_DEFER_SUM 16384.0f   // a tile whose row sum of exp2(score - reference) reaches this moves the reference (fp16 P < 65504)
 
 // D = head dim (64 or 128).  K tile row stride D+8 halves (144 / 272 B: conflict-free ds_read_b128).
 // QB = 32-query blocks per wave (1 or 2).  With QB = 2 every K / V^T fragment read from LDS feeds two MFMAs and the
@@ -49,14 +50,21 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         const int qi = q0 + b * 32 + l31;
         const f16* qp = q + ((size_t)frame * S + (qi < S ? qi : 0)) * ldq + head * D + lh * 8;
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) qf[b][kk] = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
+        for (int kk = 0; kk < KK; ++kk) {
+            // Q is held pre-multiplied by c = scale * log2(e) (one more fp16 rounding of Q, random, 2^-11 relative): the
+            // MFMA then yields the scores in the exp2 domain and, with the accumulator started at -m, already minus the
+            // running maximum -- no per-score VALU work before v_exp_f32 (this kernel is bound by VALU issue, not by MFMA)
+            const f16x8 v = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[b][kk][e] = (f16)((float)v[e] * c);
+        }
     }
 
     f32x16 o[QB][DB];
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        m_run[b] = -1e30f; l_run[b] = 0.f;
+        m_run[b] = 0.f; l_run[b] = 0.f;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -66,17 +74,36 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     // loader mapping: K tile = 64 keys x D/8 chunks(16 B); V^T tile = D rows x 8 chunks; NCH chunks per thread each
     constexpr int CPR = D / 8;
     f16x8 gk[NCH], gv[NCH];
-    auto load_tile = [&](int k0) {
+    // per-thread source pointers of tile 0, advanced by one tile per load (64 keys: 64 K rows / 128 bytes along a V^T row):
+    // 4 64-bit adds per tile instead of the address arithmetic from scratch; only a tile that reaches beyond S is
+    // bounds-checked (wave-uniform branch)
+    const f16* kptr[NCH];
+    const f16* vptr[NCH];
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int cidx = tid + 256 * i;
-            const int krow = cidx / CPR, kcol = cidx - krow * CPR;
-            const int key = k0 + krow;
-            gk[i] = (key < S) ? *(const f16x8*)(kbase + (size_t)key * ldk + kcol * 8) : zero8;
-            const int vrow = cidx >> 3, vcol = cidx & 7;   // V^T: row = d, 8 consecutive keys
-            const int kc = k0 + vcol * 8;
-            gv[i] = (kc < S) ? *(const f16x8*)(vbase + (size_t)vrow * S + kc) : zero8;
+    for (int i = 0; i < NCH; ++i) {
+        const int cidx = tid + 256 * i;
+        const int krow = cidx / CPR, kcol = cidx - krow * CPR;
+        kptr[i] = kbase + (size_t)krow * ldk + kcol * 8;
+        vptr[i] = vbase + (size_t)(cidx >> 3) * S + (cidx & 7) * 8;   // V^T: row = d, 8 consecutive keys
+    }
+    const size_t kstep = (size_t)ATT_TILE * ldk;
+    auto load_tile = [&](int k0) {
+        if (__builtin_amdgcn_readfirstlane(k0 + ATT_TILE <= S)) {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                gk[i] = *(const f16x8*)kptr[i];
+                gv[i] = *(const f16x8*)vptr[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                const int cidx = tid + 256 * i;
+                gk[i] = (k0 + cidx / CPR < S) ? *(const f16x8*)kptr[i] : zero8;
+                gv[i] = (k0 + (cidx & 7) * 8 < S) ? *(const f16x8*)vptr[i] : zero8;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) { kptr[i] += kstep; vptr[i] += ATT_TILE; }
     };
     auto store_tile = [&](int buf) {
         f16* sK = sKb + buf * ATT_TILE * ATT_KSTR;
@@ -111,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #pragma unroll
             for (int b = 0; b < QB; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[b][ts][r] = 0.f;
+                for (int r = 0; r < 16; ++r) s[b][ts][r] = -m_run[b];
             const f16* kp = sKb + buf * ATT_TILE * ATT_KSTR + (ts * 32 + l31) * ATT_KSTR + lh * 8;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
@@ -133,36 +160,52 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                         if (key >= S) s[b][ts][r] = -1e30f;
                     }
         }
+        // s = score * c - m_run (exp2 domain), and the probabilities are v_exp_f32 of the accumulators as they are.  m_run is
+        // a REFERENCE, not the maximum: it is the first tile's row maximum and moves only when a tile's probabilities come
+        // near the fp16 range (row sum of the tile >= 2^ATT_DEFER; then the true maximum is taken, O, l and this tile's
+        // scores are rescaled by the same factor and the tile's probabilities recomputed) -- the quotient O / l does not
+        // depend on the reference, fp16 keeps its relative precision at any magnitude, l and O are fp32.  So the common tile
+        // needs no row maximum at all: one compare of the row sum it computes anyway (this kernel is VALU-issue bound).
         f16x8 pf[QB][2][2];
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
-            float mx = s[b][0][0];
-#pragma unroll
-            for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][ts][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // the running max changes in few tiles once it has settled: rescale O only then (alpha == 1 exactly otherwise)
-            if (__any(mx > m_run[b])) {
-                const float m_new = fmaxf(m_run[b], mx);
-                const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * c);
-                m_run[b] = m_new;
-                l_run[b] *= alpha;
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[b][db][r] *= alpha;
-            }
-            const float mc = m_run[b] * c;
             float psum = 0.f;
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[b][ts][r], c, -mc));   // raw v_exp_f32: arguments are <= 0
+                    const float p = __builtin_amdgcn_exp2f(s[b][ts][r]);   // raw v_exp_f32
                     psum += p;
                     pf[b][ts][r >> 3][r & 7] = (f16)p;
                 }
+            const float ptot = psum + __shfl_xor(psum, 32, 64);           // both key halves of the query row
+            const bool move = !(ptot < ATT_DEFER_SUM) || t == 0;           // (NaN-safe; tile 0: m_run = 0 is no reference yet)
+            if (__any(move)) {
+                asm volatile("; reference moves" ::: "memory");
+                float mx = s[b][0][0];
+#pragma unroll
+                for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][ts][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float delta = move ? mx : 0.f;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m_run[b] += delta;
+                l_run[b] *= alpha;
+#pragma unroll
+                for (int db = 0; db < DB; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[b][db][r] *= alpha;
+                psum = 0.f;
+#pragma unroll
+                for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(s[b][ts][r] - delta);
+                        psum += p;
+                        pf[b][ts][r >> 3][r & 7] = (f16)p;
+                    }
+            }
             l_run[b] += psum;
         }
 
@@ -205,10 +248,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         }
     }
 }
+
 template <int D, int QB>
 static int launch_attn_spatial(const void* q, const void* k, const void* vt, void* out, int nframes, int heads, int S,
                                int ldq, int ldk, int ldo, float c, hipStream_t st) {
-    constexpr int LDS = 2 * (ATT_TILE * (D + 8) + D * ATT_VSTR) * 2;
+    constexpr int LDS0 = 2 * (ATT_TILE * (D + 8) + D * ATT_VSTR) * 2;
+    static int pad = -1;
+    if (pad < 0) { const char* e = getenv("MOFA_ATTN_LDS_PAD"); pad = e ? atoi(e) : 0; }
+    const int LDS = LDS0 + pad;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
