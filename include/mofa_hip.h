@@ -98,7 +98,10 @@ int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
  * (The MOFA ControlNet trunk is built with heads (5,10,10,20) -- FlowControlNet calls super().__init__()
  *  without arguments, svdxt_..._norefine.py:213 -> controlnet_sdv.py:180 -- so its 1280-channel level runs
  *  10 heads x 128; the SVD-XT UNet runs 64 everywhere.)
- * vt is V transposed per frame: vt[((frame*heads + head)*head_dim + d)*S + key] = [frame][C][S]. */
+ * vt is V transposed per frame: vt[((frame*heads + head)*head_dim + d)*S + key] = [frame][C][S].
+ * scale > 0: softmax(scale * Q K^T) V.  scale <= 0: q already holds Q * head_dim^-0.5 * log2(e) -- the caller folded
+ * that constant into its Q projection weights (blocks.SelfAttn(fold_q_scale=True)), so the kernel neither multiplies nor
+ * re-rounds Q; with scale > 0 Q is multiplied by scale * log2(e) and rounded to fp16 once more inside the kernel. */
 int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out,
                           int nframes, int heads, int head_dim, int S, int ldq, int ldk, int ldo, float scale,
                           mofa_stream_t stream);

@@ -253,14 +253,21 @@ class CrossAttnVec:
 
 
 class SelfAttn:
-    def __init__(self, s, heads):
-        w = torch.cat([s.get("to_q.weight"), s.get("to_k.weight"), s.get("to_v.weight")], 0)
-        self.wqkv = s.dev(pack_linear(w))
-        self.to_out = Linear(s.sub("to_out.0"))
+    def __init__(self, s, heads, fold_q_scale=False):
+        """fold_q_scale: multiply the Q projection by head_dim^-0.5 * log2(e) at load time (fp32, rounded to fp16 once,
+        each weight independently -- the effect on Q averages over the C input channels and is far below Q's own fp16
+        rounding), so the spatial attention kernel takes Q as is (``ops.attn_spatial(prescaled=True)``)."""
+        wq = s.get("to_q.weight")
         self.heads = heads
-        self.C = w.shape[0] // 3
+        self.C = wq.shape[0]
         self.head_dim = self.C // heads      # diffusers: attention_head_dim = out_channels // num_attention_heads
         assert self.head_dim in (64, 128), f"unsupported head dim {self.head_dim}"
+        self.q_prescaled = bool(fold_q_scale)
+        if fold_q_scale:
+            wq = (wq.float() * (self.head_dim ** -0.5 * ops.Q_FOLD_LOG2E)).to(wq.dtype)
+        w = torch.cat([wq, s.get("to_k.weight"), s.get("to_v.weight")], 0)
+        self.wqkv = s.dev(pack_linear(w))
+        self.to_out = Linear(s.sub("to_out.0"))
 
     def qkv(self, x):
         qkv = ops.igemm(x, self.wqkv)
@@ -288,7 +295,7 @@ class TransformerSpatioTemporal:
         self.proj_in, self.proj_out = Linear(s.sub("proj_in")), Linear(s.sub("proj_out"))
         b = s.sub("transformer_blocks.0")
         self.norm1, self.norm3 = LayerNorm(b.sub("norm1")), LayerNorm(b.sub("norm3"))
-        self.attn1, self.attn2, self.ff = SelfAttn(b.sub("attn1"), heads), CrossAttnVec(b.sub("attn2")), GegluFF(b.sub("ff"))
+        self.attn1, self.attn2, self.ff = SelfAttn(b.sub("attn1"), heads, fold_q_scale=True), CrossAttnVec(b.sub("attn2")), GegluFF(b.sub("ff"))
         t = s.sub("temporal_transformer_blocks.0")
         self.norm_in, self.tnorm1, self.tnorm3 = LayerNorm(t.sub("norm_in")), LayerNorm(t.sub("norm1")), LayerNorm(t.sub("norm3"))
         self.ff_in, self.tattn1, self.tattn2, self.tff = (GegluFF(t.sub("ff_in")), SelfAttn(t.sub("attn1"), heads),
@@ -315,7 +322,7 @@ class TransformerSpatioTemporal:
         h = self.proj_in(h)
         # --- spatial BasicTransformerBlock ---
         q, k, v = self.attn1.qkv(self.norm1(h))
-        a = ops.attn_spatial(q, k, v, N, self.heads, HW, head_dim=self.attn1.head_dim)
+        a = ops.attn_spatial(q, k, v, N, self.heads, HW, head_dim=self.attn1.head_dim, prescaled=self.attn1.q_prescaled)
         h = self.attn1.to_out(a, r1=h, s1=1.0, rowvec=v_sp, rv=(T * HW, 1, 1, BIG))      # + attn1 + attn2
         h = self.ff(self.norm3(h), r1=h, s1=1.0)                                          # x_spatial
         # --- TemporalBasicTransformerBlock on h + pos[t] ---

@@ -51,12 +51,16 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         const f16* qp = q + ((size_t)frame * S + (qi < S ? qi : 0)) * ldq + head * D + lh * 8;
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
-            // Q is held pre-multiplied by c = scale * log2(e) (one more fp16 rounding of Q, random, 2^-11 relative): the
+            // Q is held pre-multiplied by c = scale * log2(e) (here: one more fp16 rounding of Q, random, 2^-11 relative --
+            // callers that can fold c into their Q projection pass scale <= 0 and skip it): the
             // MFMA then yields the scores in the exp2 domain and, with the accumulator started at -m, already minus the
             // running maximum -- no per-score VALU work before v_exp_f32 (this kernel is bound by VALU issue, not by MFMA)
             const f16x8 v = (qi < S) ? *(const f16x8*)(qp + kk * 16) : zero8;
+            qf[b][kk] = v;
+            if (c != 1.0f) {                               // (c == 1: the caller folded scale * log2(e) into the Q projection)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) qf[b][kk][e] = (f16)((float)v[e] * c);
+                for (int e = 0; e < 8; ++e) qf[b][kk][e] = (f16)((float)v[e] * c);
+            }
         }
     }
 
@@ -274,7 +278,8 @@ extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* v
                                      int head_dim, int S, int ldq, int ldk, int ldo, float scale, mofa_stream_t stream) {
     if (!q || !k || !vt || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
     if (S % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
-    const float c = scale * 1.4426950408889634f;
+    // scale <= 0: q already holds Q * head_dim^-0.5 * log2(e) (folded into the projection weights: no rounding of Q here)
+    const float c = scale > 0.f ? scale * 1.4426950408889634f : 1.0f;
     // 64 queries per wave (256-row workgroups: +6-7 % at S = 9216 / 2304) when S tiles by 256 with <= 1/16 waste and the
     // grid still gives >= 4 workgroups per CU; MOFA_ATTN_QB=1|2 forces either
     static int force_qb = -1;

@@ -210,11 +210,15 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
 
 
 # ---- attention -----------------------------------------------------------------------------------------
-def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None):
-    """q/k/v: [nframes*S, heads*head_dim] column blocks (views allowed); scale defaults to head_dim**-0.5."""
+Q_FOLD_LOG2E = 1.4426950408889634
+
+
+def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, prescaled=False):
+    """q/k/v: [nframes*S, heads*head_dim] column blocks (views allowed); scale defaults to head_dim**-0.5.
+    prescaled: q already holds Q * head_dim**-0.5 * log2(e) (the constant folded into the Q projection weights)."""
     lib = L.load()
     Cc = heads * head_dim
-    scale = head_dim ** -0.5 if scale is None else scale
+    scale = -1.0 if prescaled else (head_dim ** -0.5 if scale is None else scale)
     st = L.stream_ptr()
     vt = torch.empty((nframes * Cc, S), dtype=F16, device=q.device)
     L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, Cc // 64, S, _ld(v), st), "mofa_transpose_v_f16")

@@ -79,9 +79,11 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
     return y.permute(0, 2, 1).reshape(nframes * HW, C).to(F16)
 
 
-def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None):
+def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, prescaled=False):
     assert head_dim in (64, 128) and S % 8 == 0
     scale = head_dim ** -0.5 if scale is None else scale
+    if prescaled:                       # q holds Q * head_dim^-0.5 * log2(e): softmax in base 2
+        scale = 0.6931471805599453
 
     def split(t):
         return t.float().reshape(nframes, S, heads, head_dim).permute(0, 2, 1, 3)
@@ -147,7 +149,11 @@ def cast_f32_to_f16(x):
     return x.half()
 
 
-NAMES = ["axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
+def resize_nearest_f32(x, h, w):
+    return torch.nn.functional.interpolate(x[None].float(), size=(h, w), mode="nearest")[0]
+
+
+NAMES = ["resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
          "tokens_to_nchw", "patchify", "filter1d_reflect", "resize_bicubic_ac"]
 
 

@@ -108,8 +108,10 @@ def test_pipeline_conditioning_rng_order_and_pil(emu):
     assert rel_l2(emb2, emb) < 2e-2 and rel_l2(il2, il) < 2e-2
     with pytest.raises(ValueError):
         pipe._conditioning(None, None, None, H, W, 0.02, None)
-    with pytest.raises(ValueError):
-        pipe._conditioning(torch.rand(1, 3, H + 8, W), None, None, H, W, 0.02, None)
+    # a tensor of another size is resized by nearest neighbour, as VaeImageProcessor.preprocess does for tensors
+    big = torch.nn.functional.interpolate(img, size=(2 * H, 2 * W), mode="nearest")
+    emb3, il3 = pipe._conditioning(big, None, None, H, W, 0.02, torch.Generator().manual_seed(13))
+    assert rel_l2(il3, il) < 1e-6
 
 
 def test_temb_batch_row_vector_addressing(emu):

@@ -165,6 +165,53 @@ def test_attn_spatial_online_softmax_rescale(ops):
     _close(out, ref, tol=4e-3, what="attn spatial rescale")
 
 
+@pytest.mark.parametrize("hd,qb", [(64, 1), (64, 2), (128, 1)])
+@pytest.mark.parametrize("pattern", ["rising", "falling", "spikes"])
+def test_attn_spatial_reference_moves(ops, hd, qb, pattern, monkeypatch):
+    """The kernel exponentiates scores relative to a REFERENCE that is only moved when a key tile's probabilities near the
+    fp16 range.  Logits spanning hundreds of units: rising along the keys (the reference must move tile after tile, each
+    time rescaling O and l), falling (everything after the first tiles underflows to 0 exactly as in the reference), and
+    isolated spikes in late tiles -- against fp32 softmax attention."""
+    S = 1024 if qb == 2 else 200                       # 64 queries per wave need S % 256 == 0 and enough workgroups
+    frames, heads = (64, 4) if qb == 2 else (2, 1)
+    Cc = heads * hd
+    g = torch.Generator().manual_seed(77)
+    q = torch.randn(frames * S, Cc, generator=g) * 2.0
+    k = torch.randn(frames * S, Cc, generator=g)
+    v = torch.randn(frames * S, Cc, generator=g)
+    pos = torch.arange(S).repeat(frames).float()
+    if pattern == "rising":
+        gain = 0.5 + 6.0 * pos / S
+    elif pattern == "falling":
+        gain = 6.5 - 6.0 * pos / S
+    else:
+        gain = torch.where((pos % 97) == 96, torch.tensor(8.0), torch.tensor(0.5))
+    k = k * gain[:, None]
+    qkv = torch.cat([q, k, v], 1).half()
+    d = qkv.to(DEV)
+    out = ops.attn_spatial(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S, head_dim=hd)
+    qf, kf, vf = [t.float().reshape(frames, S, heads, hd).transpose(1, 2) for t in d.split(Cc, dim=1)]   # fp32, on the GPU
+    ref, top = [], 0.0
+    for f0 in range(0, frames, 8):
+        logits = (qf[f0:f0 + 8] @ kf[f0:f0 + 8].transpose(-1, -2)) * hd ** -0.5
+        top = max(top, logits.abs().max().item())
+        ref.append((torch.softmax(logits, -1) @ vf[f0:f0 + 8]).transpose(1, 2).reshape(-1, Cc))
+    assert top > 40                                     # well outside what fp16 probabilities hold without moving
+    _close(out, torch.cat(ref, 0), tol=4e-3, what=f"attn spatial reference moves ({pattern})")
+    # the production form: head_dim^-0.5 * log2(e) folded into Q before its (single) fp16 rounding, 1.5 x the logits
+    from mofa_video_amd.ops import Q_FOLD_LOG2E
+    qs = (d[:, :Cc].float() * 1.5 * (hd ** -0.5 * Q_FOLD_LOG2E)).half()
+    out = ops.attn_spatial(qs, d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S, head_dim=hd, prescaled=True)
+    qf = qs.float().reshape(frames, S, heads, hd).transpose(1, 2)
+    ref, top = [], 0.0
+    for f0 in range(0, frames, 8):
+        logits = (qf[f0:f0 + 8] @ kf[f0:f0 + 8].transpose(-1, -2)) * 0.6931471805599453    # exp2 domain -> natural
+        top = max(top, logits.abs().max().item())
+        ref.append((torch.softmax(logits, -1) @ vf[f0:f0 + 8]).transpose(1, 2).reshape(-1, Cc))
+    assert top > 60
+    _close(out, torch.cat(ref, 0), tol=4e-3, what=f"attn spatial, Q pre-scaled, reference moves ({pattern})")
+
+
 @pytest.mark.parametrize("T,HW,heads,clips,hd", [(25, 37, 2, 2, 64), (8, 16, 1, 2, 64), (32, 5, 3, 1, 64), (1, 9, 1, 1, 64),
                                                  (25, 19, 2, 2, 128), (32, 3, 1, 1, 128)])
 def test_attn_temporal(ops, T, HW, heads, clips, hd):
