@@ -18,27 +18,27 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     } while (0)
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf GELU as diffusers' GEGLU uses it: gelu(x) = 0.5 * (x + |x| * erf(|x| / sqrt2)).  erf(z) on [0, 3] is an odd
-// minimax polynomial z * P(z^2) of degree 17 (|error| <= 2.9e-5, fitted in tools/fit_erf.py) and 1 beyond: 14 full-rate
-// VALU operations that hipcc packs two elements at a time (v_pk_fma_f32), no transcendental.  The previous
-// Abramowitz-Stegun 7.1.26 form needed v_exp_f32 + v_rcp_f32 (quarter rate): the GEGLU epilogue evaluates this
-// 4 * C times per token and was VALU-bound on it.  |gelu error| <= 6.1e-5 absolute (fp16 rounding of an O(1) result:
-// 2.4e-4).
-__device__ __forceinline__ float gelu_erf_f(float x) {
-    const float ax = fabsf(x);
-    const float z = fminf(ax * 0.70710678118654752f, 3.0f);
-    const float u = z * z;
-    float p = 4.074214033e-08f;
-    p = fmaf(p, u, -1.944823907e-06f);
-    p = fmaf(p, u, 4.106053893e-05f);
-    p = fmaf(p, u, -5.110369530e-04f);
-    p = fmaf(p, u, 4.235427827e-03f);
-    p = fmaf(p, u, -2.510286123e-02f);
-    p = fmaf(p, u, 1.110793352e-01f);
-    p = fmaf(p, u, -3.753148615e-01f);
-    p = fmaf(p, u, 1.128268480e+00f);
-    return 0.5f * fmaf(ax, z * p, x);
+// erf GELU as diffusers' GEGLU uses it: gelu(x) = x * Phi(x), Phi(x) = 0.5 + 0.5 erf(x / sqrt2) ~= 0.5 + w Q(w^2) with
+// w = x clamped to +-3 sqrt2.  Q is the odd degree-17 minimax polynomial of erf on [0, 3] (tools/fit_erf.py, |erf error|
+// <= 2.9e-5) with the 1/sqrt2 argument scale and the factor 0.5 folded into its coefficients, so the sign needs no
+// |x| / copysign handling and the whole thing is 1 v_med3 + 11 full-rate multiply-adds that hipcc packs two elements at a
+// time (v_pk_fma_f32) -- no transcendental (v_exp / v_rcp are quarter rate, and the GEGLU epilogue of the implicit GEMM is
+// bound by VALU issue: 4 * C of these per token).  |gelu error| <= 5.0e-5 absolute (fp16 rounding of an O(1) result: 2.4e-4).
+__device__ __forceinline__ float gelu_phi_f(float x) {
+    const float w = __builtin_amdgcn_fmed3f(x, -4.2426405f, 4.2426405f);
+    const float u = w * w;
+    float q = 5.626766414e-11f;
+    q = fmaf(q, u, -5.371867839e-09f);
+    q = fmaf(q, u, 2.268295702e-07f);
+    q = fmaf(q, u, -5.646214049e-06f);
+    q = fmaf(q, u, 9.359061369e-05f);
+    q = fmaf(q, u, -1.109400182e-03f);
+    q = fmaf(q, u, 9.818118997e-03f);
+    q = fmaf(q, u, -6.634692103e-02f);
+    q = fmaf(q, u, 3.989031613e-01f);
+    return fmaf(w, q, 0.5f);
 }
+__device__ __forceinline__ float gelu_erf_f(float x) { return x * gelu_phi_f(x); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -526,7 +526,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         // epilogue cost in K tiles per epilogue kind (index = kind): 4-wave tiles (their epilogue overlaps the co-resident
         // workgroup's K loop) / the 8-wave tile
         static const double epi4[9] = {2.0, 3.5, 4.0, 4.0, 3.5, 4.0, 4.5, 4.5, 4.0};
-        static const double epi8[9] = {2.2, 5.2, 5.2, 6.0, 5.6, 5.5, 5.5, 6.3, 3.3};   // ([4]: fitted to the N = 320 choice, not the 2.6 measured)
+        static const double epi8[9] = {2.2, 5.2, 5.2, 6.0, 5.6, 5.5, 5.5, 6.3, 2.4};   // ([4]: fitted to the N = 320 choice, not the 2.6 measured)
         const double nk = (double)(Ktot / 64);
         double best = 0;
         for (int k = 0; k < 2; ++k) {

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
     // tile, which is what the row-vector epilogue cost (15-19 k cycles against 5 k for the plain one).
     auto epilogue_light = [&](auto ac, auto un, f32x16 (&acc)[MI][NJ], const int mw, const int nw, const int idx_u) __attribute__((always_inline)) {
         constexpr bool UNI = decltype(un)::v != 0;
+        constexpr bool SACC1 = GEGLU && UNI;                      // (GEGLU kind: `un` says s_acc == 1, the multiplies drop out)
         // lane-derived LDS / global offsets are recomputed per tile from a laundered lane id: hoisted out of the tile loop
         // they stay live across the K loop and get spilled to scratch (and reloaded here, latency-bound)
         // (row-vector kinds only, the ones that spilled: elsewhere the hoisted offsets fit and recomputing them costs 500-900
@@ -371,33 +372,41 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
 #pragma unroll
                 for (int g = 0; g < 4; ++g) bv[j][g] += rv[j][g];
         }
+        // GEGLU kind (32 output columns per row and accumulator row block): stores without an LDS transpose.  After fp16 packing a lane holds columns 8 g + 4 lh .. + 3 (g = 0..3) of row l31 of
+        // a 32 x 32 accumulator block; one v_permlane32_swap per dword between the registers of groups 2 k and 2 k + 1
+        // (upper half of the first <-> lower half of the second) leaves lanes 0-31 with columns 16 k .. 16 k + 7 and lanes
+        // 32-63 with 16 k + 8 .. 16 k + 15 of their row: ONE 16-byte store per lane and group pair, 32 bytes per row and
+        // instruction, a row's 128-byte line completed by 4 consecutive instructions of the same wave.
+        auto store_pair = [&](f16x4 g0, f16x4 g1, int m, int n0) __attribute__((always_inline)) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x2 a2 = __builtin_bit_cast(u32x2, g0), b2 = __builtin_bit_cast(u32x2, g1);
+            const auto rx = __builtin_amdgcn_permlane32_swap(a2[0], b2[0], false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(a2[1], b2[1], false, false);
+            const u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
+            const int n = n0 + 8 * lh;
+            if (m < a.M && n + 8 <= nout) *(u32x4*)(out + (size_t)m * a.ldo + n) = v;
+        };
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
+            const int m = mw + 32 * i + l31;
             if constexpr (GEGLU) {
-                // value tile j = 0, gate tile j = 1 (weight rows interleaved in blocks of 32 at load time); the outputs
-                // of accumulator rows i (even) and i + 1 share one scratch image: columns 0..31 / 32..63
+                // value tile j = 0, gate tile j = 1 (weight rows interleaved in blocks of 32 at load time)
+                f16x4 o[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f16x4 o;
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        o[e] = (f16)(saccv * (acc[i][0][4 * g + e] + bv[0][g][e]) *
-                                     gelu_erf_f(saccv * (acc[i][1][4 * g + e] + bv[1][g][e])));
-                    *(f16x4*)(scr + h16_off(l31, 8 * (i & 1) + 2 * g + lh)) = o;
-                }
-                if (i & 1) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const int row = 8 * p + (lane >> 3), blk = lane & 7;
-                        const f16x8 v = *(const f16x8*)(scr + row * 128 + ((blk ^ ((row >> 1) & 7)) << 4));
-                        const int m = mw + 32 * (i - 1 + (blk >> 2)) + row;
-                        const int n = nw / 2 + 8 * (blk & 3);
-                        f16x8 o = v;
-                        if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-                        if (m < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = acc[i][0][4 * g + e] + bv[0][g][e], gate = acc[i][1][4 * g + e] + bv[1][g][e];
+                        if constexpr (SACC1) o[g][e] = (f16)(val * (gate * gelu_phi_f(gate)));
+                        else o[g][e] = (f16)(saccv * val * gelu_erf_f(saccv * gate));
                     }
-                }
+                store_pair(o[0], o[1], m, nw / 2);
+                store_pair(o[2], o[3], m, nw / 2 + 16);
             } else {
+                // 64 output columns per row: through the scratch (32 x 64 fp16 transpose), so that a store instruction
+                // covers 8 whole 128-byte lines.  (The register-only form above was measured here too: 16 instructions of
+                // 32 partial lines each cost 7 500 cycles per tile against 5 300 -- the texture path pays per line.)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -415,10 +424,10 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
                 for (int p = 0; p < 4; ++p) {
                     const int row = 8 * p + (lane >> 3), blk = lane & 7;
                     const f16x8 v = *(const f16x8*)(scr + row * 128 + ((blk ^ ((row >> 1) & 7)) << 4));
-                    const int m = mw + 32 * i + row, n = nw + 8 * blk;
+                    const int mr = mw + 32 * i + row, n = nw + 8 * blk;
                     f16x8 o = v;
                     if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-                    if (m < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
+                    if (mr < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
                 }
             }
         }
@@ -557,19 +566,11 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
             if (RV && idx_u >= 0) epilogue_residual(IC<1>{}, acc, mw, nw, idx_u);
             else epilogue_residual(IC<0>{}, acc, mw, nw, 0);
         } else if constexpr (GEGLU) {
-            epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
-        } else if constexpr (RV) {                                 // uniform dispatch: activation and UNI are compiled in
-            if (idx_u >= 0) {
-                if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<1>{}, acc, mw, nw, idx_u);
-                else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<1>{}, acc, mw, nw, idx_u);
-                else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<1>{}, acc, mw, nw, idx_u);
-                else epilogue_light(IC<MOFA_ACT_GELU>{}, IC<1>{}, acc, mw, nw, idx_u);
-            } else {
-                if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
-                else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<0>{}, acc, mw, nw, 0);
-                else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<0>{}, acc, mw, nw, 0);
-                else epilogue_light(IC<MOFA_ACT_GELU>{}, IC<0>{}, acc, mw, nw, 0);
-            }
+            if (a.s_acc == 1.0f) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<1>{}, acc, mw, nw, 0);
+            else epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
+        } else if constexpr (RV) {                                 // (row vector + activation launches run on the 4-wave tile)
+            if (idx_u >= 0) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<1>{}, acc, mw, nw, idx_u);
+            else epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
         } else {
             if (a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, 0);
             else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<0>{}, acc, mw, nw, 0);
@@ -651,7 +652,7 @@ static bool igemm8_eligible(const mofa_igemm_args* a, int kind, long long Ktot) 
     if (a->r1 && ((a->ldr1 & 7) || (((size_t)a->r1) & 15))) return false;
     if (a->r2 && ((a->ldr2 & 7) || (((size_t)a->r2) & 15))) return false;
     if (a->bias && (((size_t)a->bias) & 15)) return false;
-    if ((a->r1 || a->r2) && a->act != MOFA_ACT_NONE) return false;        // residual kinds carry no activation code here
+    if ((a->r1 || a->r2 || a->rowvec) && a->act != MOFA_ACT_NONE) return false;   // only the plain kind carries activation code here
     if (a->rowvec && (((size_t)a->rowvec) & 15)) return false;
     if ((long long)a->N * Ktot * 2 >= (1ll << 32) || (((size_t)a->w) & 15)) return false;
     if (a->mode == MOFA_MODE_CONV3X3) {

@@ -96,6 +96,11 @@ def test_plain_gemm_every_tile_every_kind(ops, tile, kind):
     M, N, K = 10317, 2056, 192
     x, w = _h(M, K, seed=1), _h(N, K, seed=2, scale=0.1)
     bias, kw, apply = _epilogue(kind, M, N)
+    if kind == "rvusilu" and tile == "256x256":         # row vector + activation: 4-wave tiles only, a forced 256x256 is refused
+        from mofa_video_amd.lib import MofaHipError
+        with pytest.raises(MofaHipError):
+            ops.igemm(x, w, bias, tile=TILES[tile], **kw)
+        return
     out = ops.igemm(x, w, bias, tile=TILES[tile], **kw)
     _close(out, apply(x.float() @ w.float().t()), what=f"plain {tile} {kind}")
 
