@@ -256,10 +256,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 template <int D, int QB>
 static int launch_attn_spatial(const void* q, const void* k, const void* vt, void* out, int nframes, int heads, int S,
                                int ldq, int ldk, int ldo, float c, hipStream_t st) {
-    constexpr int LDS0 = 2 * (ATT_TILE * (D + 8) + D * ATT_VSTR) * 2;
-    static int pad = -1;
-    if (pad < 0) { const char* e = getenv("MOFA_ATTN_LDS_PAD"); pad = e ? atoi(e) : 0; }
-    const int LDS = LDS0 + pad;
+    constexpr int LDS = 2 * (ATT_TILE * (D + 8) + D * ATT_VSTR) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
