@@ -110,7 +110,27 @@ __global__ void ss_fill_kernel(const float* __restrict__ flow, int* __restrict__
         }
 }
 
-// order every target's segment by key = corner*HW + source (insertion sort; segments are short)
+// order every target's segment by key = corner*HW + source (keys are distinct).  Segments are short for real flows (a
+// handful of sources per pixel): insertion sort.  A strongly convergent flow can put up to 4 HW entries on one pixel, where
+// the quadratic sort of one thread would run for seconds -- beyond SS_INSERTION_MAX entries the segment is heap-sorted in
+// place instead (O(n log n): 36 864 entries ~ 1 M steps).  Same result either way (a total order on distinct keys).
+#define SS_INSERTION_MAX 48
+__device__ __forceinline__ void ss_sift_down(int* keys, float* wts, int root, int n) {
+    const int kr = keys[root];
+    const float wr = wts[root];
+    int hole = root;
+    for (;;) {
+        int child = 2 * hole + 1;
+        if (child >= n) break;
+        if (child + 1 < n && keys[child + 1] > keys[child]) ++child;
+        if (keys[child] <= kr) break;
+        keys[hole] = keys[child];
+        wts[hole] = wts[child];
+        hole = child;
+    }
+    keys[hole] = kr;
+    wts[hole] = wr;
+}
 __global__ void ss_sort_kernel(int* __restrict__ ws, int HW, long long per) {
     const int i = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -120,17 +140,29 @@ __global__ void ss_sort_kernel(int* __restrict__ ws, int HW, long long per) {
     int* keys = base + 3 * HW + 1;
     float* wts = (float*)(base + 3 * HW + 1 + 4 * HW);
     const int a = offset[t], b = offset[t + 1];
-    for (int j = a + 1; j < b; ++j) {
-        const int kj = keys[j];
-        const float wj = wts[j];
-        int m = j - 1;
-        while (m >= a && keys[m] > kj) {
-            keys[m + 1] = keys[m];
-            wts[m + 1] = wts[m];
-            --m;
+    if (b - a <= SS_INSERTION_MAX) {
+        for (int j = a + 1; j < b; ++j) {
+            const int kj = keys[j];
+            const float wj = wts[j];
+            int m = j - 1;
+            while (m >= a && keys[m] > kj) {
+                keys[m + 1] = keys[m];
+                wts[m + 1] = wts[m];
+                --m;
+            }
+            keys[m + 1] = kj;
+            wts[m + 1] = wj;
         }
-        keys[m + 1] = kj;
-        wts[m + 1] = wj;
+    } else {
+        int* k = keys + a;
+        float* w = wts + a;
+        const int n = b - a;
+        for (int r = n / 2 - 1; r >= 0; --r) ss_sift_down(k, w, r, n);
+        for (int end = n - 1; end > 0; --end) {
+            const int kt = k[0]; k[0] = k[end]; k[end] = kt;
+            const float wt = w[0]; w[0] = w[end]; w[end] = wt;
+            ss_sift_down(k, w, 0, end);
+        }
     }
 }
 

@@ -334,6 +334,28 @@ def test_softsplat_gather_vs_oracle(ops, H, W, C, mag):
     assert torch.equal(out, out2)
 
 
+def test_softsplat_convergent_flow(ops):
+    """every source splats onto (nearly) one pixel: segments of up to 4 HW entries on a target -- the per-target ordering
+    must stay bounded in time (heap sort beyond 48 entries) and equal the oracle; run to run bit-identical"""
+    import time
+    from oracle.softsplat import softsplat
+    H, W, C = 72, 128, 64
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    flow = torch.stack([40.3 - xs, 30.6 - ys], 0)[None].repeat(2, 1, 1, 1)       # all sources -> (40.3, 30.6)
+    flow[1] = flow[1] * 0.9                                                       # second flow: a tight cluster
+    feat = _h(1, C, H, W, seed=45)
+    tok = feat[0].permute(1, 2, 0).reshape(H * W, C).contiguous()
+    out = ops.softsplat_avg_tokens(tok.to(DEV), flow.to(DEV), H, W)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    out2 = ops.softsplat_avg_tokens(tok.to(DEV), flow.to(DEV), H, W)
+    torch.cuda.synchronize()
+    assert time.time() - t0 < 1.0                        # the quadratic sort took seconds on 36 864 entries
+    assert torch.equal(out, out2)
+    ref = torch.stack([softsplat(feat.float(), flow[i:i + 1], None, "avg")[0] for i in range(2)])
+    _close(out, ref.permute(0, 2, 3, 1).reshape(2 * H * W, C), tol=1.5e-3, what="softsplat, convergent flow")
+
+
 def test_softsplat_scatter_vs_oracle(ops):
     from oracle.softsplat import softsplat_sum
     N, C, H, W = 2, 7, 12, 20
