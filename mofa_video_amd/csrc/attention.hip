@@ -334,125 +334,125 @@ extern "C" int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int he
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Temporal attention: sequence = the T frames of one (clip, pixel, head).  One wave per sequence:
-// lane (i = lane&31, hf = lane>>5): query i, keys [16*hf, 16*hf+16), output dims [32*hf, 32*hf+32).
+// Temporal attention: sequence = the T <= 32 frames of one (clip, pixel, head).  One wave per sequence, on the matrix
+// cores: S^T = K Q^T (one 32 x 32 tile, D / 16 MFMAs; a lane owns one query, the two lane halves disjoint keys), softmax
+// per lane, O^T = V^T P^T (D / 32 d-blocks x 2 MFMAs) with P straight from the S^T accumulators -- the same fragment
+// algebra as attn_spatial_kernel on a single key tile.  K goes to LDS as it is ([key][D + 8]), V is written TRANSPOSED
+// ([d][key], 2-byte scatter: 25 small writes per lane) so that its fragments are 8-byte row reads.  The r01 kernel did
+// the two products with fp32 VALU FMAs (2 048 per lane and sequence = 8 192 cycles per wave for 12.8 KB of traffic):
+// VALU-bound at 2.5 TB/s, not HBM-bound as its roofline entry said.
+// Tq query frames (rows of q / out, clip stride Tq*HW), T key/value frames (rows of k / v, clip stride T*HW): Tq < T when
+// the clip's frames are sharded over ranks and K|V were all-gathered.  key_mask: bit j clear = key frame j does not exist
+// (padding rows of uneven frame shards in the gathered buffer: never read, weight exactly 0).
 // ---------------------------------------------------------------------------------------------------
+#define ATT_TVSTR 36   // V^T row stride in halves (72 B: the 32 lanes of a half read 32 distinct bank pairs)
 template <int D, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                  const f16* __restrict__ v, f16* __restrict__ out,
                                                                  long long nseq, int Tq, int T, int HW, int heads, int ld,
                                                                  int ldkv, int ldo, float scale, unsigned key_mask) {
-    // Tq query frames (rows of q/out, clip stride Tq*HW), T key/value frames (rows of k/v, clip stride T*HW):
-    // Tq < T when the clip's frames are sharded over ranks and K/V were all-gathered.  key_mask: bit j clear = key frame j
-    // does not exist (padding rows of uneven frame shards in the gathered buffer: never read, weight exactly 0).
     constexpr int DC = D / 8;       // 16-byte chunks per row
-    constexpr int DH = D / 2;       // output dims per lane half
-    __shared__ __attribute__((aligned(16))) f16 sK[WPB][32 * D];
-    __shared__ __attribute__((aligned(16))) f16 sV[WPB][32 * D];
+    constexpr int KK = D / 16;      // MFMA k-steps of S^T
+    constexpr int DB = D / 32;      // 32-wide output d-blocks
+    constexpr int KSTR = D + 8;     // K row stride in halves (conflict-free ds_read_b128)
+    __shared__ __attribute__((aligned(16))) f16 sK[WPB][32 * KSTR];
+    __shared__ __attribute__((aligned(16))) f16 sV[WPB][D * ATT_TVSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long seq = (long long)blockIdx.x * WPB + wave;
-    const bool active = seq < nseq;
-    const int i = lane & 31, hf = lane >> 5;
+    if (seq >= nseq) return;                                       // (no workgroup barrier below: LDS regions are per wave)
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int head = (int)(seq % heads);
+    const long long bp = seq / heads;
+    const int p = (int)(bp % HW);
+    const int b = (int)(bp / HW);
+    const size_t base = ((size_t)b * T * HW + p);                  // k / v token row of frame 0
+    const size_t qbase = ((size_t)b * Tq * HW + p);                // q / out token row of frame 0
+    f16* wK = sK[wave];
+    f16* wV = sV[wave];
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    size_t base = 0, qbase = 0;
-    int head = 0;
-    if (active) {
-        head = (int)(seq % heads);
-        const long long bp = seq / heads;
-        const int p = (int)(bp % HW);
-        const int b = (int)(bp / HW);
-        base = ((size_t)b * T * HW + p);    // k/v token row of frame 0
-        qbase = ((size_t)b * Tq * HW + p);  // q/out token row of frame 0
-        for (int c = lane; c < T * DC; c += 64) {
-            const int t = c / DC, cc = c - t * DC;
-            if (!((key_mask >> t) & 1u)) continue;
-            const size_t row = base + (size_t)t * HW;
-            *(f16x8*)&sK[wave][t * D + cc * 8] = *(const f16x8*)(k + row * ldkv + head * D + cc * 8);
-            *(f16x8*)&sV[wave][t * D + cc * 8] = *(const f16x8*)(v + row * ldkv + head * D + cc * 8);
+    // ---- K rows and V^T columns of the existing key frames; everything else stays zero (a masked key's probability is
+    //      exactly 0, but 0 * NaN from never-written memory would not be) ----
+    for (int c = lane; c < 32 * DC; c += 64) *(f16x8*)&wK[(c / DC) * KSTR + (c % DC) * 8] = zero8;
+    for (int c = lane; c < D * ATT_TVSTR / 8; c += 64) *(f16x8*)&wV[c * 8] = zero8;
+    // Q fragments (B operand of S^T): lane (query l31, half lh) holds Q[q][16 kk + 8 lh .. + 8)
+    f16x8 qf[KK];
+    {
+        const f16* qp = q + (qbase + (size_t)(l31 < Tq ? l31 : 0) * HW) * ld + head * D + lh * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[kk] = l31 < Tq ? *(const f16x8*)(qp + kk * 16) : zero8;
+    }
+    for (int c = lane; c < T * DC; c += 64) {
+        const int t = c / DC, cc = c - t * DC;
+        if (!((key_mask >> t) & 1u)) continue;
+        const size_t row = base + (size_t)t * HW;
+        const f16x8 kv = *(const f16x8*)(k + row * ldkv + head * D + cc * 8);
+        const f16x8 vv = *(const f16x8*)(v + row * ldkv + head * D + cc * 8);
+        *(f16x8*)&wK[t * KSTR + cc * 8] = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wV[(cc * 8 + e) * ATT_TVSTR + t] = vv[e];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's LDS writes are in place
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- S^T: s[r] = score(key = (r & 3) + 8 (r >> 2) + 4 lh, query = l31) ----
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+        const f16* kp = wK + l31 * KSTR + lh * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            const f16x8 kf = *(const f16x8*)(kp + kk * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s, 0, 0, 0);
         }
     }
-    __syncthreads();
-    if (!active) return;
-
-    float qv[D];
-    if (i < Tq) {
-        const f16* qp = q + (qbase + (size_t)i * HW) * ld + head * D;
-#pragma unroll
-        for (int cidx = 0; cidx < DC; ++cidx) {
-            const f16x8 a = *(const f16x8*)(qp + cidx * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qv[cidx * 8 + e] = (float)a[e] * scale;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < D; ++e) qv[e] = 0.f;
-    }
-    float sc[16];
+    const float c2 = scale * 1.4426950408889634f;
     float mx = -1e30f;
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = hf * 16 + jj;
-        float acc = 0.f;
-        if (j < T && ((key_mask >> j) & 1u)) {
-            const f16* kp = &sK[wave][j * D];
-#pragma unroll
-            for (int cidx = 0; cidx < DC; ++cidx) {
-                const f16x8 a = *(const f16x8*)(kp + cidx * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc = fmaf(qv[cidx * 8 + e], (float)a[e], acc);
-            }
-        } else {
-            acc = -1e30f;
-        }
-        sc[jj] = acc;
-        mx = fmaxf(mx, acc);
+    for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (key >= T || !((key_mask >> key) & 1u)) s[r] = -1e30f;
+        mx = fmaxf(mx, s[r]);
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mc = mx * c2;
     float sum = 0.f;
+    f16x8 pf[2];
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        sc[jj] = __expf(sc[jj] - mx);
-        sum += sc[jj];
+    for (int r = 0; r < 16; ++r) {
+        const float pr = __builtin_amdgcn_exp2f(fmaf(s[r], c2, -mc));   // masked keys: exp2(-huge) = 0
+        sum += pr;
+        pf[r >> 3][r & 7] = (f16)pr;
     }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
 
-    float ov[DH];
+    // ---- O^T[d][q] += V^T[d][key] P^T[key][q]; k-slot (8 lh + jj) of MFMA u = key 16 u + 4 lh + (jj & 3) + 8 (jj >> 2) ----
+    f32x16 o[DB];
 #pragma unroll
-    for (int e = 0; e < DH; ++e) ov[e] = 0.f;
+    for (int db = 0; db < DB; ++db) {
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const float other = __shfl_xor(sc[jj], 32, 64);
-        const float p_lo = hf == 0 ? sc[jj] : other;   // key jj
-        const float p_hi = hf == 0 ? other : sc[jj];   // key 16 + jj
-        if (jj < T && ((key_mask >> jj) & 1u)) {
-            const f16* vp = &sV[wave][jj * D + hf * DH];
+        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
+        const f16* vp = wV + (db * 32 + l31) * ATT_TVSTR + 4 * lh;
 #pragma unroll
-            for (int cidx = 0; cidx < DH / 8; ++cidx) {
-                const f16x8 a = *(const f16x8*)(vp + cidx * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov[cidx * 8 + e] = fmaf(p_lo, (float)a[e], ov[cidx * 8 + e]);
-            }
-        }
-        if (16 + jj < T && ((key_mask >> (16 + jj)) & 1u)) {
-            const f16* vp = &sV[wave][(16 + jj) * D + hf * DH];
-#pragma unroll
-            for (int cidx = 0; cidx < DH / 8; ++cidx) {
-                const f16x8 a = *(const f16x8*)(vp + cidx * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ov[cidx * 8 + e] = fmaf(p_hi, (float)a[e], ov[cidx * 8 + e]);
-            }
+        for (int u = 0; u < 2; ++u) {
+            const f16x4 lo = *(const f16x4*)(vp + u * 16), hi = *(const f16x4*)(vp + u * 16 + 8);
+            const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[db], 0, 0, 0);
         }
     }
-    if (i < Tq) {
-        f16* op = out + (qbase + (size_t)i * HW) * ldo + head * D + hf * DH;
+    if (l31 < Tq) {
+        f16* op = out + (qbase + (size_t)l31 * HW) * ldo + head * D;
 #pragma unroll
-        for (int cidx = 0; cidx < DH / 8; ++cidx) {
-            f16x8 a;
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a[e] = (f16)(ov[cidx * 8 + e] * inv);
-            *(f16x8*)(op + cidx * 8) = a;
-        }
+            for (int qd = 0; qd < 4; ++qd) {
+                f16x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (f16)(o[db][4 * qd + e] * inv);
+                *(f16x4*)(op + db * 32 + 8 * qd + 4 * lh) = w;
+            }
     }
 }
 
