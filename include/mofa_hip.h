@@ -98,14 +98,16 @@ int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
  * (The MOFA ControlNet trunk is built with heads (5,10,10,20) -- FlowControlNet calls super().__init__()
  *  without arguments, svdxt_..._norefine.py:213 -> controlnet_sdv.py:180 -- so its 1280-channel level runs
  *  10 heads x 128; the SVD-XT UNet runs 64 everywhere.)
- * vt is V transposed per frame: vt[((frame*heads + head)*head_dim + d)*S + key] = [frame][C][S].
+ * v is read as it is, row-major [tokens][ldv] like q and k (the transposed fragments of the PV product come from the LDS
+ * transpose read of gfx950; no pre-transposed copy of V).
  * scale > 0: softmax(scale * Q K^T) V.  scale <= 0: q already holds Q * head_dim^-0.5 * log2(e) -- the caller folded
  * that constant into its Q projection weights (blocks.SelfAttn(fold_q_scale=True)), so the kernel neither multiplies nor
  * re-rounds Q; with scale > 0 Q is multiplied by scale * log2(e) and rounded to fp16 once more inside the kernel. */
-int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out,
-                          int nframes, int heads, int head_dim, int S, int ldq, int ldk, int ldo, float scale,
+int mofa_attn_spatial_f16(const void* q, const void* k, const void* v, void* out,
+                          int nframes, int heads, int head_dim, int S, int ldq, int ldk, int ldv, int ldo, float scale,
                           mofa_stream_t stream);
-/* [tokens][ld] columns in blocks of 64 (ncb = C/64 blocks) -> vt layout above */
+/* [tokens][ld] columns in blocks of 64 (ncb = C/64 blocks) -> vt[((frame*ncb + cb)*64 + d)*S + key] = [frame][C][S]: the
+ * weight operand of the VAE mid-block attention's second implicit GEMM (vae.py); the attention kernels do not need it */
 int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int ncb, int S, int ldv, mofa_stream_t stream);
 /* temporal self-attention over T frames per (clip, pixel, head), head_dim 64 or 128, T <= 32.
  * k/v: token row of (clip b, frame t, pixel p) = (b*T + t)*HW + p, leading dim ldkv.

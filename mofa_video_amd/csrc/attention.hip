@@ -1,8 +1,9 @@
 // Attention kernels for gfx950 (head_dim 64).
 //
 // mofa_attn_spatial_f16: flash-style self-attention over the S = h*w tokens of one frame.
-//   One workgroup = 4 waves = 128 (or 256: two 32-query blocks per wave) query rows of one (frame, head); K and V^T
-//   tiles of 64 keys are staged through double-buffered LDS.  Scores are computed TRANSPOSED (S^T = K . Q^T, MFMA
+//   One workgroup = 4 waves = 128 (or 256: two 32-query blocks per wave) query rows of one (frame, head); K and V
+//   tiles of 64 keys are staged through double-buffered LDS (V row-major; its transposed fragments come from the LDS
+//   transpose read ds_read_b64_tr_b16).  Scores are computed TRANSPOSED (S^T = K . Q^T, MFMA
 //   32x32x16 f16) so every lane owns one query row: the softmax statistics are per-lane scalars
 //   (one cross-half exchange per tile) and the probabilities are already laid out as the B operand of
 //   O^T += V^T . P^T -- the k-slot -> key permutation of that MFMA is chosen to match the accumulator
@@ -14,7 +15,6 @@
 
 #include "common.h"
 
-#define ATT_VSTR 68   // V^T tile row stride (halves): 136 B, conflict-free ds_read_b64
 #define ATT_TILE 64
 #define ATT_DEFER_SUM 16384.0f   // a tile whose row sum of exp2(score - reference) reaches this moves the reference (fp16 P < 65504)
 
@@ -22,17 +22,30 @@
 // QB = 32-query blocks per wave (1 or 2).  With QB = 2 every K / V^T fragment read from LDS feeds two MFMAs and the
 // per-tile costs (tile loads, LDS store, barrier, 24 fragment reads) are paid once per 64 queries of a wave: used when
 // a frame has enough query rows to fill the chip with 256-row workgroups.
+// V stays ROW-major ([key][d], as the QKV projection writes it): the V^T fragments of O^T += V^T P^T are read with
+// ds_read_b64_tr_b16, the LDS transpose read of gfx950.  Semantics (measured, tools note in DESIGN.md): within each group of
+// 16 lanes, lane j supplies the address of an 8-byte chunk C_j (4 halves); lane i = 4 q + e of the group receives
+// (C_q[e], C_{q+4}[e], C_{q+8}[e], C_{q+12}[e]).  With lane j = q + 4 r addressing V[k0 + r][d0 + 4 q .. + 3], lane i gets
+// V[k0 .. k0 + 3][d0 + i]: four consecutive keys of ONE column d -- a V^T fragment piece -- from row-major data.  Row stride
+// D + 32 halves: the 32 lanes of a half-wave (4 key rows x 8 chunks) then hit 32 distinct bank pairs.
+typedef short att_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f16x4 lds_read_tr4(const f16* p) {
+    const att_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)p);
+    return __builtin_bit_cast(f16x4, v);
+}
+
 template <int D, int QB>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
-                                                              const f16* __restrict__ vt, f16* __restrict__ out,
-                                                              int heads, int S, int ldq, int ldk, int ldo, float c) {
+                                                              const f16* __restrict__ v, f16* __restrict__ out,
+                                                              int heads, int S, int ldq, int ldk, int ldv, int ldo, float c) {
     constexpr int ATT_KSTR = D + 8;
+    constexpr int ATT_VSTR = D + 32; // V tile row stride (halves)
     constexpr int KK = D / 16;       // MFMA k-steps of S^T
     constexpr int DB = D / 32;       // 32-wide output d-blocks
-    constexpr int NCH = D / 32;      // 16-byte chunks per thread per tile (K and V^T each)
+    constexpr int NCH = D / 32;      // 16-byte chunks per thread per tile (K and V each)
     extern __shared__ __attribute__((aligned(16))) char smem_att[];
     f16* sKb = (f16*)smem_att;                          // [2][64 * ATT_KSTR]
-    f16* sVb = sKb + 2 * ATT_TILE * ATT_KSTR;           // [2][D * ATT_VSTR]
+    f16* sVb = sKb + 2 * ATT_TILE * ATT_KSTR;           // [2][64 * ATT_VSTR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -40,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
 
     const f16* kbase = k + (size_t)frame * S * ldk + head * D;
-    const f16* vbase = vt + ((size_t)(frame * heads + head) * D) * S;
+    const f16* vbase = v + (size_t)frame * S * ldv + head * D;
 
     // Q fragments (B operand of S^T): lane (query l31, half lh) holds Q[q][16*kk + 8*lh .. +8)
     f16x8 qf[QB][KK];
@@ -78,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     // loader mapping: K tile = 64 keys x D/8 chunks(16 B); V^T tile = D rows x 8 chunks; NCH chunks per thread each
     constexpr int CPR = D / 8;
     f16x8 gk[NCH], gv[NCH];
-    // per-thread source pointers of tile 0, advanced by one tile per load (64 keys: 64 K rows / 128 bytes along a V^T row):
+    // per-thread source pointers of tile 0 (K and V rows have the same shape: 64 keys x D), advanced by 64 rows per load:
     // 4 64-bit adds per tile instead of the address arithmetic from scratch; only a tile that reaches beyond S is
     // bounds-checked (wave-uniform branch)
     const f16* kptr[NCH];
@@ -88,9 +101,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         const int cidx = tid + 256 * i;
         const int krow = cidx / CPR, kcol = cidx - krow * CPR;
         kptr[i] = kbase + (size_t)krow * ldk + kcol * 8;
-        vptr[i] = vbase + (size_t)(cidx >> 3) * S + (cidx & 7) * 8;   // V^T: row = d, 8 consecutive keys
+        vptr[i] = vbase + (size_t)krow * ldv + kcol * 8;
     }
-    const size_t kstep = (size_t)ATT_TILE * ldk;
+    const size_t kstep = (size_t)ATT_TILE * ldk, vstep = (size_t)ATT_TILE * ldv;
     auto load_tile = [&](int k0) {
         if (__builtin_amdgcn_readfirstlane(k0 + ATT_TILE <= S)) {
 #pragma unroll
@@ -98,32 +111,31 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                 gk[i] = *(const f16x8*)kptr[i];
                 gv[i] = *(const f16x8*)vptr[i];
             }
-        } else {
+        } else {                                            // rows of keys beyond S are zero (K: score masked; V: 0 * p)
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                const int cidx = tid + 256 * i;
-                gk[i] = (k0 + cidx / CPR < S) ? *(const f16x8*)kptr[i] : zero8;
-                gv[i] = (k0 + (cidx & 7) * 8 < S) ? *(const f16x8*)vptr[i] : zero8;
+                const bool ok = k0 + (tid + 256 * i) / CPR < S;
+                gk[i] = ok ? *(const f16x8*)kptr[i] : zero8;
+                gv[i] = ok ? *(const f16x8*)vptr[i] : zero8;
             }
         }
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) { kptr[i] += kstep; vptr[i] += ATT_TILE; }
+        for (int i = 0; i < NCH; ++i) { kptr[i] += kstep; vptr[i] += vstep; }
     };
     auto store_tile = [&](int buf) {
         f16* sK = sKb + buf * ATT_TILE * ATT_KSTR;
-        f16* sV = sVb + buf * D * ATT_VSTR;
+        f16* sV = sVb + buf * ATT_TILE * ATT_VSTR;
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int cidx = tid + 256 * i;
             const int krow = cidx / CPR, kcol = cidx - krow * CPR;
             *(f16x8*)&sK[krow * ATT_KSTR + kcol * 8] = gk[i];
-            const int vrow = cidx >> 3, vcol = cidx & 7;
-            f16x4 lo = {gv[i][0], gv[i][1], gv[i][2], gv[i][3]};
-            f16x4 hi = {gv[i][4], gv[i][5], gv[i][6], gv[i][7]};
-            *(f16x4*)&sV[vrow * ATT_VSTR + vcol * 8] = lo;
-            *(f16x4*)&sV[vrow * ATT_VSTR + vcol * 8 + 4] = hi;
+            *(f16x8*)&sV[krow * ATT_VSTR + kcol * 8] = gv[i];
         }
     };
+    // transpose-read address of this lane inside a V tile (see lds_read_tr4): key row (lane & 15) >> 2 (+ 4 lh), column
+    // chunk 4 ((lane & 15) & 3) of the 16-column group (lane >> 4) & 1
+    const int tr_off = (((lane & 15) >> 2) + 4 * lh) * ATT_VSTR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
     const int ntiles = (S + ATT_TILE - 1) / ATT_TILE;
     load_tile(0);
@@ -217,13 +229,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         //      32*ts + 16*u + 4*lh + (jj&3) + 8*(jj>>2), identical for both operands ---------------
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-            const f16* vp = sVb + buf * D * ATT_VSTR + (db * 32 + l31) * ATT_VSTR + 4 * lh;
+            const f16* vp = sVb + buf * ATT_TILE * ATT_VSTR + tr_off + db * 32;
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const f16x4 lo = *(const f16x4*)(vp + ts * 32 + u * 16);
-                    const f16x4 hi = *(const f16x4*)(vp + ts * 32 + u * 16 + 8);
+                    const f16x4 lo = lds_read_tr4(vp + (ts * 32 + u * 16) * ATT_VSTR);        // keys k0 + 4 lh + 0..3
+                    const f16x4 hi = lds_read_tr4(vp + (ts * 32 + u * 16 + 8) * ATT_VSTR);    // keys k0 + 4 lh + 8..11
                     const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                     for (int b = 0; b < QB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b][ts][u], o[b][db], 0, 0, 0);
@@ -254,9 +266,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 }
 
 template <int D, int QB>
-static int launch_attn_spatial(const void* q, const void* k, const void* vt, void* out, int nframes, int heads, int S,
-                               int ldq, int ldk, int ldo, float c, hipStream_t st) {
-    constexpr int LDS = 2 * (ATT_TILE * (D + 8) + D * ATT_VSTR) * 2;
+static int launch_attn_spatial(const void* q, const void* k, const void* v, void* out, int nframes, int heads, int S,
+                               int ldq, int ldk, int ldv, int ldo, float c, hipStream_t st) {
+    constexpr int LDS = 2 * (ATT_TILE * (D + 8) + ATT_TILE * (D + 32)) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
@@ -265,16 +277,17 @@ static int launch_attn_spatial(const void* q, const void* k, const void* vt, voi
         attr_set = true;
     }
     dim3 grid(cdiv(S, 128 * QB), heads, nframes);
-    hipLaunchKernelGGL((attn_spatial_kernel<D, QB>), grid, dim3(256), LDS, st, (const f16*)q, (const f16*)k, (const f16*)vt,
-                       (f16*)out, heads, S, ldq, ldk, ldo, c);
+    hipLaunchKernelGGL((attn_spatial_kernel<D, QB>), grid, dim3(256), LDS, st, (const f16*)q, (const f16*)k, (const f16*)v,
+                       (f16*)out, heads, S, ldq, ldk, ldv, ldo, c);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
 
-extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* vt, void* out, int nframes, int heads,
-                                     int head_dim, int S, int ldq, int ldk, int ldo, float scale, mofa_stream_t stream) {
-    if (!q || !k || !vt || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
-    if (S % 8 != 0 || ldq % 8 != 0 || ldk % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
+extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* v, void* out, int nframes, int heads,
+                                     int head_dim, int S, int ldq, int ldk, int ldv, int ldo, float scale,
+                                     mofa_stream_t stream) {
+    if (!q || !k || !v || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
+    if (ldq % 8 != 0 || ldk % 8 != 0 || ldv % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
     // scale <= 0: q already holds Q * head_dim^-0.5 * log2(e) (folded into the projection weights: no rounding of Q here)
     const float c = scale > 0.f ? scale * 1.4426950408889634f : 1.0f;
     // 64 queries per wave (256-row workgroups: +6-7 % at S = 9216 / 2304) when S tiles by 256 with <= 1/16 waste and the
@@ -284,14 +297,17 @@ extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* v
     const bool two = force_qb ? force_qb == 2
                               : ((long long)cdiv(S, 256) * 256 * 16 <= (long long)S * 17 && (long long)cdiv(S, 256) * heads * nframes >= 1024);
     if (head_dim == 64)
-        return two ? launch_attn_spatial<64, 2>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream)
-                   : launch_attn_spatial<64, 1>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
-    if (head_dim == 128) return launch_attn_spatial<128, 1>(q, k, vt, out, nframes, heads, S, ldq, ldk, ldo, c, (hipStream_t)stream);
+        return two ? launch_attn_spatial<64, 2>(q, k, v, out, nframes, heads, S, ldq, ldk, ldv, ldo, c, (hipStream_t)stream)
+                   : launch_attn_spatial<64, 1>(q, k, v, out, nframes, heads, S, ldq, ldk, ldv, ldo, c, (hipStream_t)stream);
+    if (head_dim == 128)
+        return launch_attn_spatial<128, 1>(q, k, v, out, nframes, heads, S, ldq, ldk, ldv, ldo, c, (hipStream_t)stream);
     return MOFA_EINVAL;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// V [tokens][ldv] columns c (64-column blocks) -> V^T [(frame*ncb + cb)*64 + d][S]  (= [frame][C][S], any head dim)
+// V [tokens][ldv] columns c (64-column blocks) -> V^T [(frame*ncb + cb)*64 + d][S]  (= [frame][C][S], any head dim).
+// Not used by the attention kernels any more (they read V row-major through the LDS transpose read): the VAE mid-block
+// attention, which materialises its scores with two implicit-GEMM launches, takes V^T as the weight operand of the second.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void transpose_v_kernel(const f16* __restrict__ v, f16* __restrict__ vt, int heads,
                                                           int S, int ldv) {
@@ -337,15 +353,14 @@ extern "C" int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int he
 // Temporal attention: sequence = the T <= 32 frames of one (clip, pixel, head).  One wave per sequence, on the matrix
 // cores: S^T = K Q^T (one 32 x 32 tile, D / 16 MFMAs; a lane owns one query, the two lane halves disjoint keys), softmax
 // per lane, O^T = V^T P^T (D / 32 d-blocks x 2 MFMAs) with P straight from the S^T accumulators -- the same fragment
-// algebra as attn_spatial_kernel on a single key tile.  K goes to LDS as it is ([key][D + 8]), V is written TRANSPOSED
-// ([d][key], 2-byte scatter: 25 small writes per lane) so that its fragments are 8-byte row reads.  The r01 kernel did
+// algebra as attn_spatial_kernel on a single key tile.  K and V go to LDS as they are ([key][D + 8] / [key][D + 32]); the
+// V^T fragments come from the LDS transpose read (lds_read_tr4).  The r01 kernel did
 // the two products with fp32 VALU FMAs (2 048 per lane and sequence = 8 192 cycles per wave for 12.8 KB of traffic):
 // VALU-bound at 2.5 TB/s, not HBM-bound as its roofline entry said.
 // Tq query frames (rows of q / out, clip stride Tq*HW), T key/value frames (rows of k / v, clip stride T*HW): Tq < T when
 // the clip's frames are sharded over ranks and K|V were all-gathered.  key_mask: bit j clear = key frame j does not exist
 // (padding rows of uneven frame shards in the gathered buffer: never read, weight exactly 0).
 // ---------------------------------------------------------------------------------------------------
-#define ATT_TVSTR 36   // V^T row stride in halves (72 B: the 32 lanes of a half read 32 distinct bank pairs)
 template <int D, int WPB>
 __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                                  const f16* __restrict__ v, f16* __restrict__ out,
@@ -355,8 +370,9 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
     constexpr int KK = D / 16;      // MFMA k-steps of S^T
     constexpr int DB = D / 32;      // 32-wide output d-blocks
     constexpr int KSTR = D + 8;     // K row stride in halves (conflict-free ds_read_b128)
+    constexpr int VSTR = D + 32;    // V row stride in halves (see lds_read_tr4)
     __shared__ __attribute__((aligned(16))) f16 sK[WPB][32 * KSTR];
-    __shared__ __attribute__((aligned(16))) f16 sV[WPB][D * ATT_TVSTR];
+    __shared__ __attribute__((aligned(16))) f16 sV[WPB][32 * VSTR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long seq = (long long)blockIdx.x * WPB + wave;
     if (seq >= nseq) return;                                       // (no workgroup barrier below: LDS regions are per wave)
@@ -373,8 +389,10 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
 
     // ---- K rows and V^T columns of the existing key frames; everything else stays zero (a masked key's probability is
     //      exactly 0, but 0 * NaN from never-written memory would not be) ----
-    for (int c = lane; c < 32 * DC; c += 64) *(f16x8*)&wK[(c / DC) * KSTR + (c % DC) * 8] = zero8;
-    for (int c = lane; c < D * ATT_TVSTR / 8; c += 64) *(f16x8*)&wV[c * 8] = zero8;
+    for (int c = lane; c < 32 * DC; c += 64) {
+        *(f16x8*)&wK[(c / DC) * KSTR + (c % DC) * 8] = zero8;
+        *(f16x8*)&wV[(c / DC) * VSTR + (c % DC) * 8] = zero8;
+    }
     // Q fragments (B operand of S^T): lane (query l31, half lh) holds Q[q][16 kk + 8 lh .. + 8)
     f16x8 qf[KK];
     {
@@ -389,8 +407,7 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
         const f16x8 kv = *(const f16x8*)(k + row * ldkv + head * D + cc * 8);
         const f16x8 vv = *(const f16x8*)(v + row * ldkv + head * D + cc * 8);
         *(f16x8*)&wK[t * KSTR + cc * 8] = kv;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) wV[(cc * 8 + e) * ATT_TVSTR + t] = vv[e];
+        *(f16x8*)&wV[t * VSTR + cc * 8] = vv;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this wave's LDS writes are in place
     __builtin_amdgcn_wave_barrier();
@@ -434,10 +451,10 @@ __global__ __launch_bounds__(64 * WPB) void attn_temporal_kernel(const f16* __re
     for (int db = 0; db < DB; ++db) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-        const f16* vp = wV + (db * 32 + l31) * ATT_TVSTR + 4 * lh;
+        const f16* vp = wV + (((lane & 15) >> 2) + 4 * lh) * VSTR + db * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const f16x4 lo = *(const f16x4*)(vp + u * 16), hi = *(const f16x4*)(vp + u * 16 + 8);
+            const f16x4 lo = lds_read_tr4(vp + (u * 16) * VSTR), hi = lds_read_tr4(vp + (u * 16 + 8) * VSTR);
             const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[db], 0, 0, 0);
         }

@@ -42,7 +42,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 PROTOTYPES = {
     "mofa_version": [],
     "mofa_igemm_f16": [C.POINTER(IgemmArgs), _P],
-    "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_attn_temporal_masked_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint32, _P],

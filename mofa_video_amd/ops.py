@@ -220,13 +220,11 @@ def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, 
     Cc = heads * head_dim
     scale = -1.0 if prescaled else (head_dim ** -0.5 if scale is None else scale)
     st = L.stream_ptr()
-    vt = torch.empty((nframes * Cc, S), dtype=F16, device=q.device)
-    L.check(lib.mofa_transpose_v_f16(L.ptr(v), L.ptr(vt), nframes, Cc // 64, S, _ld(v), st), "mofa_transpose_v_f16")
     if out is None:
         out = torch.empty((nframes * S, Cc), dtype=F16, device=q.device)
     t0 = TIMER.start() if TIMER is not None else None
-    L.check(lib.mofa_attn_spatial_f16(L.ptr(q), L.ptr(k), L.ptr(vt), L.ptr(out), nframes, heads, head_dim, S, _ld(q),
-                                      _ld(k), _ld(out), scale, st), "mofa_attn_spatial_f16")
+    L.check(lib.mofa_attn_spatial_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nframes, heads, head_dim, S, _ld(q),
+                                      _ld(k), _ld(v), _ld(out), scale, st), "mofa_attn_spatial_f16")
     if t0 is not None:
         TIMER.stop("attn_spatial_kernel", t0, flops=4.0 * S * S * Cc * nframes)
     return out

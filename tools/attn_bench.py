@@ -42,7 +42,7 @@ def main():
         ref = torch.softmax(q @ k.t() * 0.125, dim=1) @ v
         err = (out[:S, :64].float() - ref).abs().max().item()
         digest = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12]
-        print(f"attn spatial {tag:14s} {fr}x{heads}h S={S:5d}  {t * 1e3:8.3f} ms (incl. V transpose) {4.0 * S * S * Cc * fr / t / 1e12:7.1f} TF/s"
+        print(f"attn spatial {tag:14s} {fr}x{heads}h S={S:5d}  {t * 1e3:8.3f} ms {4.0 * S * S * Cc * fr / t / 1e12:7.1f} TF/s"
               f"   max|err| vs fp32 {err:.2e}   sha1 {digest}")
 
 

@@ -64,8 +64,8 @@ def main():
         l = lib.load()
 
         def run():
-            lib.check(l.mofa_attn_spatial_f16(lib.ptr(qkv), lib.ptr(qkv[:, Cc:]), lib.ptr(vt), lib.ptr(out), fr, heads, 64, S,
-                                              3 * Cc, 3 * Cc, Cc, 0.125, lib.stream_ptr()), "attn")
+            lib.check(l.mofa_attn_spatial_f16(lib.ptr(qkv), lib.ptr(qkv[:, Cc:]), lib.ptr(qkv[:, 2 * Cc:]), lib.ptr(out), fr, heads, 64,
+                                              S, 3 * Cc, 3 * Cc, 3 * Cc, Cc, 0.125, lib.stream_ptr()), "attn")
         t = timeit(run, iters=5)
         print(f"{'attn spatial ' + tag:40s} {f'{fr}x{heads}h S={S}':34s} {t * 1e3:9.3f} {4 * S * S * 64 * heads * fr / t / 1e12:10.1f}")
         t = timeit(lambda: ops.transpose_v(qkv[:, 2 * Cc:], fr, heads, S), iters=5)
