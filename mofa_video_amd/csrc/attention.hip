@@ -38,8 +38,15 @@ template <int D, int QB>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                               const f16* __restrict__ v, f16* __restrict__ out,
                                                               int heads, int S, int ldq, int ldk, int ldv, int ldo, float c) {
-    constexpr int ATT_KSTR = D + 8;
-    constexpr int ATT_VSTR = D + 32; // V tile row stride (halves)
+    // D = 64: K / V tiles arrive by LDS-DMA (buffer_load ... lds: no VGPR staging, no per-tile address arithmetic -- the tile
+    // index is the instruction's scalar offset, rows beyond S read as zero through the descriptor's bounds check).  The DMA
+    // image is lane-linear, so rows are exactly 128 bytes and conflicts are avoided by swizzling the SOURCE chunk instead of
+    // padding: K chunk c of row r sits in slot c ^ ((r >> 1) & 7) (ds_read_b128 fragments), V's two 64-byte halves are
+    // swapped in rows with bit 1 set (the 4 key rows x 64 bytes of a transpose read then cover 4 distinct bank quarters).
+    // D = 128 (0.1 % of a clip) keeps the register-staged, padded form.
+    constexpr bool DMA = D == 64;
+    constexpr int ATT_KSTR = DMA ? D : D + 8;
+    constexpr int ATT_VSTR = DMA ? D : D + 32; // V tile row stride (halves)
     constexpr int KK = D / 16;       // MFMA k-steps of S^T
     constexpr int DB = D / 32;       // 32-wide output d-blocks
     constexpr int NCH = D / 32;      // 16-byte chunks per thread per tile (K and V each)
@@ -77,10 +84,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         }
     }
 
+    constexpr bool NEGM = D == 64;
     f32x16 o[QB][DB];
+    f32x16 negm[QB];                                      // (NEGM) -m_run[b] in all 16 registers
     float m_run[QB], l_run[QB];
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[b][r] = 0.f;
         m_run[b] = 0.f; l_run[b] = 0.f;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -137,30 +148,68 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     // chunk 4 ((lane & 15) & 3) of the 16-column group (lane >> 4) & 1
     const int tr_off = (((lane & 15) >> 2) + 4 * lh) * ATT_VSTR + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 
+    // ---- DMA form: descriptors over this (frame, head)'s K / V rows; per-lane byte offset of tile 0 ----
+    const auto rsk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (unsigned)(((size_t)(S - 1) * ldk + D) * 2), 0x00020000);
+    const auto rsv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (unsigned)(((size_t)(S - 1) * ldv + D) * 2), 0x00020000);
+    unsigned dko[2], dvo[2];                              // instruction i of this wave: tile rows (2 wave + i) * 8 + lane / 8
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i) * 8 + (lane >> 3), slot = lane & 7;
+        dko[i] = (unsigned)row * (unsigned)ldk * 2u + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+        dvo[i] = (unsigned)row * (unsigned)ldv * 2u + (unsigned)((slot ^ (4 * ((row >> 1) & 1))) * 16);
+    }
+    auto dma_tile = [&](int t, int buf) __attribute__((always_inline)) {
+        char* bk = (char*)(sKb + buf * ATT_TILE * ATT_KSTR) + (2 * wave) * 1024;
+        char* bv = (char*)(sVb + buf * ATT_TILE * ATT_VSTR) + (2 * wave) * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(bk + i * 1024), 16, dko[i],
+                                                     t * ATT_TILE * ldk * 2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(bv + i * 1024), 16, dvo[i],
+                                                     t * ATT_TILE * ldv * 2, 0, 0);
+        }
+    };
+    const int ksw = (l31 >> 1) & 7;                       // K fragment reads: slot = chunk ^ ksw
+    const int vsw = (lane >> 3) & 1;                      // V transpose reads: this lane's key row has bit 1 set -> other half
+
     const int ntiles = (S + ATT_TILE - 1) / ATT_TILE;
-    load_tile(0);
-    store_tile(0);
+    if constexpr (DMA) {
+        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        load_tile(0);
+        store_tile(0);
+    }
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int k0 = t * ATT_TILE;
-        if (t + 1 < ntiles) load_tile(k0 + ATT_TILE);
+        if (t + 1 < ntiles) {
+            if constexpr (DMA) dma_tile(t + 1, buf ^ 1);            // (the other buffer was released by the last barrier)
+            else load_tile(k0 + ATT_TILE);
+        }
 
         // ---- S^T tiles: s[b][ts][r] = score(key = k0 + 32*ts + (r&3) + 8*(r>>2) + 4*lh, query = 32*b + l31) ----
+        // the accumulators start at -m_run: NEGM keeps that as a 16-register tuple per query block (it changes only when the
+        // reference moves) and the first k-step takes it as its C operand -- no 32 v_mov per tile; the register-staged
+        // D = 128 form has no registers to spare for it
         f32x16 s[QB][2];
 #pragma unroll
         for (int ts = 0; ts < 2; ++ts) {
+            if constexpr (!NEGM) {
 #pragma unroll
-            for (int b = 0; b < QB; ++b)
+                for (int b = 0; b < QB; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[b][ts][r] = -m_run[b];
-            const f16* kp = sKb + buf * ATT_TILE * ATT_KSTR + (ts * 32 + l31) * ATT_KSTR + lh * 8;
+                    for (int r = 0; r < 16; ++r) s[b][ts][r] = -m_run[b];
+            }
+            const f16* kp = sKb + buf * ATT_TILE * ATT_KSTR + (ts * 32 + l31) * ATT_KSTR + (DMA ? 0 : lh * 8);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                const f16x8 kf = *(const f16x8*)(kp + kk * 16);
+                const f16x8 kf = *(const f16x8*)(kp + (DMA ? ((2 * kk + lh) ^ ksw) * 8 : kk * 16));
 #pragma unroll
-                for (int b = 0; b < QB; ++b) s[b][ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][kk], s[b][ts], 0, 0, 0);
+                for (int b = 0; b < QB; ++b)
+                    s[b][ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][kk], (NEGM && kk == 0) ? negm[b] : s[b][ts], 0, 0, 0);
             }
         }
         // ---- mask (tail tile only) + online softmax (per-lane query row; the two halves hold disjoint keys) ----
@@ -207,6 +256,10 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                 const float delta = move ? mx : 0.f;
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 m_run[b] += delta;
+                if constexpr (NEGM) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) negm[b][r] = -m_run[b];
+                }
                 l_run[b] *= alpha;
 #pragma unroll
                 for (int db = 0; db < DB; ++db)
@@ -229,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         //      32*ts + 16*u + 4*lh + (jj&3) + 8*(jj>>2), identical for both operands ---------------
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-            const f16* vp = sVb + buf * ATT_TILE * ATT_VSTR + tr_off + db * 32;
+            const f16* vp = sVb + buf * ATT_TILE * ATT_VSTR + tr_off + (DMA ? (db ^ vsw) : db) * 32;
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
@@ -241,7 +294,10 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                     for (int b = 0; b < QB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b][ts][u], o[b][db], 0, 0, 0);
                 }
         }
-        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        if (t + 1 < ntiles) {
+            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t + 1 have landed
+            else store_tile(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -268,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 template <int D, int QB>
 static int launch_attn_spatial(const void* q, const void* k, const void* v, void* out, int nframes, int heads, int S,
                                int ldq, int ldk, int ldv, int ldo, float c, hipStream_t st) {
-    constexpr int LDS = 2 * (ATT_TILE * (D + 8) + ATT_TILE * (D + 32)) * 2;
+    constexpr int LDS = D == 64 ? 2 * (ATT_TILE * D + ATT_TILE * D) * 2 : 2 * (ATT_TILE * (D + 8) + ATT_TILE * (D + 32)) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
