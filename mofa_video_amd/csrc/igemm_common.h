@@ -16,14 +16,20 @@ __device__ __forceinline__ RowGeo make_geo(const mofa_igemm_args& a, int m) {
     RowGeo g;
     g.a = (m < a.M) ? m : -1;
     g.b = 0;
+    // the divisors pass through an empty asm so that the reciprocal sequences of these integer divisions are set up HERE,
+    // per call (once per output tile): hoisted out of the persistent tile loop hipcc spills them to scratch and reloads
+    // them with an s_waitcnt vmcnt(0) that also drains the next tile's DMA
     if (a.mode == MOFA_MODE_CONV3X3) {
-        const int hw = a.Hout * a.Wout;
+        int hw = a.Hout * a.Wout, wout = a.Wout;
+        asm volatile("" : "+s"(hw), "+s"(wout));
         const int img = m / hw, rem = m - img * hw;
-        const int oy = rem / a.Wout;
+        const int oy = rem / wout;
         g.a = (m < a.M) ? img : -1;
-        g.b = (oy << 16) | (rem - oy * a.Wout);
+        g.b = (oy << 16) | (rem - oy * wout);
     } else if (a.mode == MOFA_MODE_CONVT3) {
-        g.b = a.T > 0 ? (m / a.HW) % a.T : 0;
+        int HW = a.HW, T = a.T;
+        asm volatile("" : "+s"(HW), "+s"(T));
+        g.b = T > 0 ? (m / HW) % T : 0;
     }
     return g;
 }
