@@ -7,13 +7,14 @@ GROUPS = {
     "read_b128": [[*range(0, 4), *range(12, 16), *range(20, 28)], [*range(4, 12), *range(16, 20), *range(28, 32)],
                   [*range(32, 36), *range(44, 48), *range(52, 60)], [*range(36, 44), *range(48, 52), *range(60, 64)]],
     "read_b64": [list(range(0, 32)), list(range(32, 64))],
+    "read_tr_b64": [list(range(0, 32)), list(range(32, 64))],   # ds_read_b64_tr_b16: 2 x 32 lanes, bank = (a / 4) mod 64
     "read_b32": [list(range(0, 32)), list(range(32, 64))],
     "write_b32": [list(range(0, 32)), list(range(32, 64))],
     "write_b64": [list(range(16 * g, 16 * g + 16)) for g in range(4)],
     "write_b128": [list(range(8 * g, 8 * g + 8)) for g in range(8)],
 }
-WIDTH = {"read_b128": 16, "read_b64": 8, "read_b32": 4, "write_b32": 4, "write_b64": 8, "write_b128": 16}
-NBANKS = {"read_b128": 64, "read_b64": 64, "read_b32": 32, "write_b32": 32, "write_b64": 32, "write_b128": 32}
+WIDTH = {"read_tr_b64": 8, "read_b128": 16, "read_b64": 8, "read_b32": 4, "write_b32": 4, "write_b64": 8, "write_b128": 16}
+NBANKS = {"read_tr_b64": 64, "read_b128": 64, "read_b64": 64, "read_b32": 32, "write_b32": 32, "write_b64": 32, "write_b128": 32}
 
 
 def cycles(kind, addr):
@@ -84,7 +85,33 @@ def f32_read(p, half, f):  # lane reads columns 8 piece + 4 half .. +3 of row 16
     return [f32_off(16 * p + (lane >> 2), 2 * (lane & 3) + half, f) for lane in range(64)]
 
 
+# ---- attention (csrc/attention.hip): V tile rows read with the LDS transpose read.  Lane j = q + 4 r of a 16-lane group
+# addresses V[k0 + r][d0 + 4 q ..], the second group of a half-wave the next 16 columns, the upper half-wave key rows + 4.
+def attn_v_tr(row_bytes, db, swz):
+    a = []
+    for lane in range(64):
+        r, q, g, lh = (lane & 15) >> 2, lane & 3, (lane >> 4) & 1, lane >> 5
+        row = r + 4 * lh
+        half = db ^ ((row >> 1) & 1) if swz else db          # DMA form: 64-byte halves swapped in rows with bit 1 set
+        a.append(row * row_bytes + half * 64 + 32 * g + 8 * q)
+    return a
+
+
+def attn_k_frag(kk, dma):                                     # K fragment: lane (key row l31, half lh) reads 16 bytes
+    a = []
+    for lane in range(64):
+        l31, lh = lane & 31, lane >> 5
+        a.append(l31 * 128 + (((2 * kk + lh) ^ ((l31 >> 1) & 7)) * 16) if dma else l31 * 144 + (2 * kk + lh) * 16)
+    return a
+
+
 if __name__ == "__main__":
+    for db in range(2):
+        report(f"attention V transpose read, padded rows (D + 32), d-block {db}", "read_tr_b64", attn_v_tr(192, db, False))
+        report(f"attention V transpose read, 128-byte rows, unswizzled, d-block {db}", "read_tr_b64", attn_v_tr(128, db, False))
+        report(f"attention V transpose read, 128-byte rows, half swap (DMA form), d-block {db}", "read_tr_b64", attn_v_tr(128, db, True))
+    for kk in range(4):
+        report(f"attention K fragment read (DMA form, source swizzle), kk = {kk}", "read_b128", attn_k_frag(kk, True))
     for kk in range(4):
         report(f"K loop fragment read, kk = {kk}", "read_b128", frag_read(kk))
     for j in range(2):
