@@ -106,6 +106,12 @@ int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
 int mofa_attn_spatial_f16(const void* q, const void* k, const void* v, void* out,
                           int nframes, int heads, int head_dim, int S, int ldq, int ldk, int ldv, int ldo, float scale,
                           mofa_stream_t stream);
+/* the same with the number of 32-query blocks per wave chosen by the caller: 0 = the launcher's rule (as above), 1 = 128-row
+ * workgroups, 2 = 256-row workgroups (head_dim 64 only).  Same result up to fp32 summation order; the parity tests drive
+ * both kernels over the bench's shapes with it. */
+int mofa_attn_spatial_qb_f16(const void* q, const void* k, const void* v, void* out,
+                             int nframes, int heads, int head_dim, int S, int ldq, int ldk, int ldv, int ldo, float scale,
+                             int query_blocks, mofa_stream_t stream);
 /* [tokens][ld] columns in blocks of 64 (ncb = C/64 blocks) -> vt[((frame*ncb + cb)*64 + d)*S + key] = [frame][C][S]: the
  * weight operand of the VAE mid-block attention's second implicit GEMM (vae.py); the attention kernels do not need it */
 int mofa_transpose_v_f16(const void* v, void* vt, int nframes, int ncb, int S, int ldv, mofa_stream_t stream);
@@ -144,6 +150,12 @@ int mofa_gn_reduce(const float* part, double* sums, int nframes, int HW, int C, 
 int mofa_gn_finalize_sums(const double* sums, const float* gamma, const float* beta, float* scale, float* shift,
                           int nframes, int C, int frames_per_stat, double count_per_group, float eps,
                           mofa_stream_t stream);
+/* fused finalize + apply (single-rank path): every workgroup combines the partial sums of its statistics set itself (fp64,
+ * fixed order) and applies y = (x - mean) * rstd * gamma + beta, optional SiLU -- no scale / shift buffers, no finalize launch.
+ * Meant for frames_per_stat * mofa_gn_nparts(HW, C) <= 512 entries (100 KB of partials re-read per workgroup from L2). */
+int mofa_gn_apply_f16(const void* x, const float* part, const float* gamma, const float* beta, void* y,
+                      int nframes, int HW, int C, int ldx, int ldy, int frames_per_stat, float eps, int silu,
+                      mofa_stream_t stream);
 /* y = x*scale[frame][c] + shift[frame][c]; optional SiLU */
 int mofa_affine_act_f16(const void* x, const float* scale, const float* shift, void* y,
                         int nframes, int HW, int C, int ldx, int ldy, int silu, mofa_stream_t stream);

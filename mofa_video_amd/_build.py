@@ -1,37 +1,56 @@
-"""Build libmofa_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libmofa_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+One object per translation unit under ``mofa_video_amd/build/`` (git-ignored), compiled in parallel, then one link:
+``build(force=True)`` is a real recompile of every kernel in about 20 s; ``force=False`` recompiles only the units whose
+sources (or shared headers) are newer than their object.  ``probe=True`` builds ``tools/libmofa_hip_probe.so`` instead:
+the same library plus the K-loop timing variants and the cycle-trace hook of tools/igemm8_probe.py (-DMOFA_PROBE), which
+the product library does not carry."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmofa_hip.so")
-SOURCES = ["igemm.hip", "igemm8.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip", "cmp_ops.hip",
-           "frontend.hip"]
+PROBE_LIB = os.path.join(HERE, "..", "tools", "libmofa_hip_probe.so")
+SOURCES = ["igemm.hip", "igemm8.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip",
+           "cmp_ops.hip", "frontend.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(CSRC, "igemm_pipe.h"),
+           os.path.join(HERE, "..", "include", "mofa_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
-                                                      os.path.join(CSRC, "igemm_common.h"),
-                                                      os.path.join(HERE, "..", "include", "mofa_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
-
-
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return LIB
+def _hipcc():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if not os.path.exists(hipcc):
-        hipcc = "hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
-    return LIB
+    return hipcc if os.path.exists(hipcc) else "hipcc"
+
+
+def build(force=False, verbose=False, probe=False):
+    objdir = os.path.join(HERE, "build", "probe" if probe else "lib")
+    os.makedirs(objdir, exist_ok=True)
+    lib = PROBE_LIB if probe else LIB
+    hdr_t = max(os.path.getmtime(h) for h in HEADERS if os.path.exists(h))
+    flags = FLAGS + (["-DMOFA_PROBE"] if probe else [])
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            jobs.append([_hipcc(), *flags, "-c", src, "-o", obj])
+    if not jobs and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(os.path.join(objdir, s.replace(".hip", ".o")))
+                                                for s in SOURCES):
+        return lib
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
+        list(ex.map(run, jobs))
+    run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *[os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES],
+         "-o", lib])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force="--incremental" not in sys.argv, verbose=True, probe="--probe" in sys.argv))

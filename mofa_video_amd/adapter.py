@@ -289,15 +289,15 @@ class _Matting:
 
 
 class LandmarkFlowControlNet(FlowControlNet):
-    @classmethod
-    def _schema(cls, config=None):
-        from . import schema
-        return schema.ldmk_controlnet_schema(config)
-
     """``FlowControlNet`` of MOFA-Video-Hybrid/models/ldmk_ctrlnet.py (= MOFA-Video-Keypoint/models/ldmk_ctrlnet.py):
     the trajectory adapter (first-frame encoder without zero convs) + landmark-image embedding added at the 320-channel
     stages + per-scale ForegroundMatting and zero-out on every warped frame.  ``forward`` adds the ``landmarks``
     argument and returns the occlusion masks 4th (:322-339, :569-570)."""
+
+    @classmethod
+    def _schema(cls, config=None):
+        from . import schema
+        return schema.ldmk_controlnet_schema(config)
 
     def __init__(self, state_dict, config=None, device="cuda", dtype=torch.float16):
         super().__init__(state_dict, config, device, dtype)

@@ -9,9 +9,9 @@
 //   O^T += V^T . P^T -- the k-slot -> key permutation of that MFMA is chosen to match the accumulator
 //   layout of S^T, so P never leaves registers.  fp32 accumulation, online softmax in exp2 domain.
 //
-// mofa_attn_temporal_f16: self-attention over the T <= 32 frames of one (clip, pixel, head); HBM-bound,
-//   one wave per sequence, VALU fp32.
-#include <stdlib.h>
+// mofa_attn_temporal_f16: self-attention over the T <= 32 frames of one (clip, pixel, head); HBM-bound, one wave per
+//   sequence on the matrix cores (S^T = K . Q^T as one 32x32 tile, softmax per lane, O^T = V^T . P^T with P taken from the
+//   S^T accumulators; V row-major in LDS, read through the LDS transpose read).
 
 #include "common.h"
 
@@ -339,25 +339,30 @@ static int launch_attn_spatial(const void* q, const void* k, const void* v, void
     return MOFA_OK;
 }
 
-extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* v, void* out, int nframes, int heads,
-                                     int head_dim, int S, int ldq, int ldk, int ldv, int ldo, float scale,
-                                     mofa_stream_t stream) {
+extern "C" int mofa_attn_spatial_qb_f16(const void* q, const void* k, const void* v, void* out, int nframes, int heads,
+                                        int head_dim, int S, int ldq, int ldk, int ldv, int ldo, float scale,
+                                        int query_blocks, mofa_stream_t stream) {
     if (!q || !k || !v || !out || nframes <= 0 || heads <= 0 || S <= 0) return MOFA_EINVAL;
     if (ldq % 8 != 0 || ldk % 8 != 0 || ldv % 8 != 0 || ldo % 4 != 0) return MOFA_EINVAL;
+    if (query_blocks < 0 || query_blocks > 2 || (query_blocks == 2 && head_dim != 64)) return MOFA_EINVAL;
     // scale <= 0: q already holds Q * head_dim^-0.5 * log2(e) (folded into the projection weights: no rounding of Q here)
     const float c = scale > 0.f ? scale * 1.4426950408889634f : 1.0f;
     // 64 queries per wave (256-row workgroups: +6-7 % at S = 9216 / 2304) when S tiles by 256 with <= 1/16 waste and the
-    // grid still gives >= 4 workgroups per CU; MOFA_ATTN_QB=1|2 forces either
-    static int force_qb = -1;
-    if (force_qb < 0) { const char* e = getenv("MOFA_ATTN_QB"); force_qb = e ? atoi(e) : 0; }
-    const bool two = force_qb ? force_qb == 2
-                              : ((long long)cdiv(S, 256) * 256 * 16 <= (long long)S * 17 && (long long)cdiv(S, 256) * heads * nframes >= 1024);
+    // grid still gives >= 4 workgroups per CU; query_blocks = 1 | 2 forces either (parity tests)
+    const bool two = query_blocks ? query_blocks == 2
+                                  : ((long long)cdiv(S, 256) * 256 * 16 <= (long long)S * 17 && (long long)cdiv(S, 256) * heads * nframes >= 1024);
     if (head_dim == 64)
         return two ? launch_attn_spatial<64, 2>(q, k, v, out, nframes, heads, S, ldq, ldk, ldv, ldo, c, (hipStream_t)stream)
                    : launch_attn_spatial<64, 1>(q, k, v, out, nframes, heads, S, ldq, ldk, ldv, ldo, c, (hipStream_t)stream);
     if (head_dim == 128)
         return launch_attn_spatial<128, 1>(q, k, v, out, nframes, heads, S, ldq, ldk, ldv, ldo, c, (hipStream_t)stream);
     return MOFA_EINVAL;
+}
+
+extern "C" int mofa_attn_spatial_f16(const void* q, const void* k, const void* v, void* out, int nframes, int heads,
+                                     int head_dim, int S, int ldq, int ldk, int ldv, int ldo, float scale,
+                                     mofa_stream_t stream) {
+    return mofa_attn_spatial_qb_f16(q, k, v, out, nframes, heads, head_dim, S, ldq, ldk, ldv, ldo, scale, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -489,11 +489,9 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         {IGEMM_KINDS(2, 2, 2), 128, 128, 256, 2 * 256 * 128, 2},   // 128^2 tile, 2 workgroups per CU
         {IGEMM_KINDS(2, 2, 3), 192, 128, 256, 2 * 320 * 128, 2},   // 192x128 tile: 2 x 80 KB = the whole LDS of a CU
     };
-    static int forced = -1;    // -1 unset; MOFA_TILE_* forced for every launch by MOFA_IGEMM_CFG; 0 = none
+    static bool ready = false;   // one-time set-up: LDS opt-in of every instantiation, CU count
     static int n_cu = 256;
-    if (forced == -1) {
-        const char* e2 = getenv("MOFA_IGEMM_CFG");
-        const int v = e2 ? atoi(e2) : 0;
+    if (!ready) {
         for (const Cfg& c : cfgs)
             for (igemm_kern_t k : c.k)
                 if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess)
@@ -503,14 +501,14 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             n_cu = cus;
-        forced = (v == MOFA_TILE_128X128 || v == MOFA_TILE_192X128 || v == MOFA_TILE_256X256) ? v : 0;
+        ready = true;
     }
     if (a->tile != 0 && a->tile != MOFA_TILE_128X128 && a->tile != MOFA_TILE_192X128 && a->tile != MOFA_TILE_256X256)
         return MOFA_EINVAL;
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const long long Ktot = (long long)taps * a->Cin;
     const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
-    int choice = a->tile ? a->tile : forced;                  // MOFA_TILE_* or 0 = cost model
+    int choice = a->tile;                                     // MOFA_TILE_* or 0 = cost model
     if (choice == 0) {
         // Tile choice = the cheapest of  rounds of resident workgroups x CU time of one round, the latter modelled as
         //   workgroups per CU x tile area x relative K-loop cost per flop x (1 + epilogue / K loop),  epilogue in K tiles:
@@ -546,7 +544,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         const int rc = igemm8_launch(a, kind, n_cu, (hipStream_t)stream);
         if (rc <= 0) return rc;                               // launched (0) or failed (< 0)
         if (a->tile == MOFA_TILE_256X256) return MOFA_EINVAL; // explicitly requested but not eligible (alignment)
-        choice = MOFA_TILE_192X128;                           // forced by environment / chosen by the model: fall back
+        choice = MOFA_TILE_192X128;                           // chosen by the model but not eligible: fall back
     }
     const Cfg* sel = &cfgs[choice == MOFA_TILE_128X128 ? 0 : 1];
     const Cfg& c = *sel;

@@ -7,27 +7,26 @@
 // 8-phase template", T3+T4+T5):
 //
 //   * wave (wm, wn) of 2 x 4 owns 128 (M) x 64 (N) outputs = 4 x 2 accumulator tiles of 32x32.  A K tile (64 deep) is
-//     consumed in FOUR PHASES, one quadrant (2 x 1 accumulator tiles, 8 MFMAs = 256 matrix-pipe cycles) each:
-//         phase 1: X half 0 x W half 0      reads X0 (8 ds_read_b128) + W0 (4)
-//         phase 2: X half 0 x W half 1      reads W1 (4)                       (X0 stays in registers)
-//         phase 3: X half 1 x W half 1      reads X1 (8)                       (W1 stays)
-//         phase 4: X half 1 x W half 0      reads nothing                      (W0 was kept since phase 1)
-//     A phase is  {fragment reads, 2 LDS-DMA instructions, s_waitcnt vmcnt(8)} s_barrier {8 MFMAs} s_barrier.
+//     consumed in TWO PHASES of 16 MFMAs (512 matrix-pipe cycles) each:
+//         phase 1: X half 0 (accumulator rows 0-1) x W     reads X0 (8 ds_read_b128) + W (8)
+//         phase 2: X half 1 (accumulator rows 2-3) x W     reads X1 (8)                       (W stays in registers)
+//     A phase is  {fragment reads, LDS-DMA issue, s_waitcnt vmcnt(8) lgkmcnt(0)} s_barrier {16 MFMAs} s_barrier.
+//     (Four phases of 8 MFMAs with quarter-tile DMA were measured in round 2: the same rate with twice the barriers.)
 //   * the two halves of the workgroup (waves 0-3 / 4-7: one wave of each per SIMD) run ONE BARRIER APART, so on every
 //     SIMD one wave is in its MFMA segment while its partner reads fragments and issues DMA; s_setprio(1) around the
 //     MFMA cluster lets the matrix pipe win the issue arbitration.
-//   * the LDS ring is 2 K tiles x 4 half tiles (X0, X1, W0, W1: 128 rows x 128 B = 16 KB each).  A half tile is
-//     released as soon as its fragments are in registers (X0, W0 after phase 1, W1 after 2, X1 after 3) and refilled
-//     two phases later; every phase issues exactly one half tile (each wave 2 DMA instructions of 8 rows):
-//         phase 1: W1 of K tile t+1     phase 2: X1 of t+1     phase 3: X0 of t+2     phase 4: W0 of t+2
-//     so every half tile has FOUR phases of flight before the single counted wait `vmcnt(8)` (= the DMA of the last
-//     four phases may stay outstanding) retires it, and it is read no earlier than the phase after that wait (the
-//     wait precedes the phase's first barrier; with the two wave groups one barrier apart that is the barrier after
-//     which the other group's reads start -- guide: "read a staged buffer one phase AFTER the wait that retires it").
-//     vmcnt is never drained inside the loop, and the stream of half tiles runs on ACROSS output tiles: while a tile's
-//     epilogue runs, the first one and a half K tiles of the workgroup's next output tile are already in flight.
-//   * two producer cursors (one per half-tile pair) walk the same persistent tile sequence as the consumer, 1 and 2 K
-//     tiles ahead; past the end of the walk they source the zero page so that the instruction count stays static.
+//   * the LDS ring is 2 K tiles x (X 256 rows + W 256 rows) x 128 B = 2 x 64 KB.  A part is released as soon as its
+//     fragments are in registers (X0 and W after phase 1, X1 after phase 2) and refilled in the NEXT phase:
+//         phase 1: X1 of K tile t+1 (2 DMA instructions per thread)     phase 2: X0 + W of K tile t+2 (2 + 4)
+//     i.e. 8 DMA instructions (1 KB each per wave) per thread and K tile, every one with about one K tile of flight
+//     before the counted wait `vmcnt(8)` (= the DMA of the last two phases may stay outstanding) retires it; it is read
+//     no earlier than the phase after that wait (the wait precedes the phase's first barrier; with the two wave groups
+//     one barrier apart that is the barrier after which the other group's reads start -- guide: "read a staged buffer
+//     one phase AFTER the wait that retires it").  vmcnt is never drained inside the loop, and the stream runs on ACROSS
+//     output tiles: while a tile's epilogue runs, the first K tiles of the workgroup's next output tile are in flight.
+//   * two producer cursors (X0 + W, X1) walk the same persistent tile sequence as the consumer, 1 and 2 K tiles ahead;
+//     past the end of the walk their rows carry the out-of-range offset (zeros through the buffer descriptor's bounds
+//     check) so that the instruction count stays static.
 //
 // Epilogue: private 4 KB LDS scratch per wave OUTSIDE the ring (160 KB = 2 x 64 KB ring + 8 x 4 KB), so nothing in the
 // epilogue aliases a DMA target and no barrier is needed inside it.  Kinds without residuals (plain, row vector, GEGLU)
@@ -36,6 +35,9 @@
 // traffic of an fp32 transpose, which is what bounds the epilogue (ds_write ~ 80 B/clk/CU).  Kinds with residuals keep
 // fp32 through the transpose (32 x 32 fp32 per pass) so that the sum is rounded once.
 // Eligibility (checked by the launcher): 16-byte aligned rows everywhere ("wide" path of igemm.hip), N % 8 == 0.
+//
+// Build variants: the K-loop timing probes and the per-segment cycle trace (VAR != 0, tools/igemm8_probe.py) are compiled
+// only with -DMOFA_PROBE into tools/libmofa_hip_probe.so; the product library holds the nine VAR = 0 kernels alone.
 #include "igemm_common.h"
 
 namespace {
@@ -596,8 +598,10 @@ static const igemm8_kern_t k_igemm8[9] = {igemm8_f16_kernel<0>, igemm8_f16_kerne
                                            igemm8_f16_kernel<6>, igemm8_f16_kernel<7>, igemm8_f16_kernel<8>};
 
 
-// diagnostic hook of tools/igemm8_probe.py (not part of the C ABI in mofa_hip.h): plain-epilogue launches run K-loop build
-// variant `var` (see the kernel's VAR) and, for var & 64, write per-segment cycle sums to `trace` ([grid][2][16] u64)
+#ifdef MOFA_PROBE
+// diagnostic hook of tools/igemm8_probe.py (tools/libmofa_hip_probe.so only; not part of the C ABI): plain-epilogue
+// launches run K-loop build variant `var` (see the kernel's VAR) and, for var & 64, write per-segment cycle sums to
+// `trace` ([grid][2][16] u64)
 static int s_probe_var = 0;
 static unsigned long long* s_probe_trace = nullptr;
 static const int k_probe_vars[] = {1, 2, 4, 8, 16, 32, 48, 64};
@@ -611,17 +615,20 @@ extern "C" int mofa_igemm8_set_probe(int var, void* trace) {
     s_probe_trace = (unsigned long long*)trace;
     return 0;
 }
+#endif
 
 int igemm8_init() {
     for (igemm8_kern_t k : k_igemm8)
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
+#ifdef MOFA_PROBE
     for (igemm8_kern_t k : k_probe_kern)
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
     for (igemm8_kern_t k : k_trace_kern)
         if (k && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
+#endif
     return MOFA_OK;
 }
 
@@ -683,12 +690,15 @@ int igemm8_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stre
     aux.xbase = (const char*)a->x - (halo ? (size_t)a->HW * a->ldx * 2 : 0);
     aux.x_bytes = (unsigned)(igemm8_rows_in(a) * a->ldx * 2 - (a->ldx - a->Cin) * 2);
     aux.w_bytes = (unsigned)((long long)a->N * taps * a->Cin * 2);
-    aux.trace = s_probe_trace;
+    aux.trace = nullptr;
     igemm8_kern_t kern = k_igemm8[kind];
+#ifdef MOFA_PROBE
+    aux.trace = s_probe_trace;
     if (kind == 0 && s_probe_var)
         for (size_t i = 0; i < sizeof(k_probe_vars) / sizeof(int); ++i)
             if (k_probe_vars[i] == s_probe_var) kern = k_probe_kern[i];
     if (s_probe_var == 64 && k_trace_kern[kind]) kern = k_trace_kern[kind];
+#endif
     int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
     if (grid < 8) grid = 8;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), LDS_BYTES, stream, *a, tilesN, (int)nt, aux);

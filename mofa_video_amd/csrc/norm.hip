@@ -1,82 +1,116 @@
 // GroupNorm(32) / LayerNorm for token-major fp16 activations (HBM-bound kernels).
 //
-// GroupNorm is three launches:
+// GroupNorm is two launches (r03; three before):
 //   1. gn_partial : per (frame, row-chunk, 256-channel block) fp32 sum / sum-of-squares per group
-//   2. gn_finalize: combine partials (per frame, or per clip of T frames for TemporalResnetBlock whose
-//                   statistics span T*H*W) -> per-(frame, channel) scale = rstd*gamma, shift = beta - mean*scale
-//   3. affine_act : y = x*scale + shift, optional SiLU
-// Deterministic (no float atomics across workgroups).
+//   2. gn_apply   : every workgroup combines the partials of ITS statistics set itself (per frame, or per clip of T frames
+//                   for TemporalResnetBlock whose statistics span T*H*W; fp64, fixed order) into scale = rstd*gamma,
+//                   shift = beta - mean*scale in LDS, then y = x*scale + shift, optional SiLU, over its rows of that frame.
+//                   The partials are a few KB..100 KB and L2 resident; recomputing them per workgroup costs less than the
+//                   18 us launch-to-launch latency of a separate one-workgroup-per-set finalize kernel (4 054 per clip).
+//   (gn_finalize / affine_act remain as separate entry points: the frame-sharded path all-reduces the sums in between.)
+// Deterministic (no float atomics across workgroups; no cross-workgroup hand-off).
 #include "common.h"
 
 #define GN_MAX_CHUNKS 128
 
+// row chunks per frame.  One partial entry (32 groups x {sum, sum of squares}) per (frame, chunk), ALL channels: few enough
+// entries that the applying kernel can combine a clip's worth itself (25 frames x 16 chunks = 400 entries = 100 KB), enough
+// workgroups (frames x chunks) to stream at HBM rate with 4 row loads in flight per thread.
 static inline int gn_nchunks(int HW) {
-    int n = cdiv(HW, 256);
-    return n > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : n;
+    const int n = HW >= 9216 ? cdiv(HW, 576) : cdiv(HW, 144);
+    const int cap = HW >= 9216 ? GN_MAX_CHUNKS : 16;
+    return n > cap ? cap : (n < 1 ? 1 : n);
 }
-extern "C" int mofa_gn_nparts(int HW, int C) { return gn_nchunks(HW) * cdiv(C, 256); }
+extern "C" int mofa_gn_nparts(int HW, int C) { (void)C; return gn_nchunks(HW); }
 
+// thread layout: cols = min(C / 8, 256) column threads (8 channels = 16 B each) x rl = 256 / cols row lanes; channels beyond
+// 2048 are covered by a second pass over the columns.  Per-thread fp32 sums over <= rows_per_chunk / rl rows, LDS tree over
+// the row lanes in fixed order, then ONE thread per group adds its channels in channel order: deterministic.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x, float* __restrict__ part, int HW,
                                                          int C, int ldx, int rows_per_chunk, int nparts) {
-    __shared__ float sS[8][256];
-    __shared__ float sQ[8][256];
+    __shared__ float sS[2048], sQ[2048];                   // [row lane][column thread][8] of the current pass
+    __shared__ float cS[8192 / 4], cQ[8192 / 4];           // per-channel totals of one pass (<= 2048 channels)
     __shared__ float gS[32], gQ[32];
-    const int tid = threadIdx.x, cx = tid & 31, ry = tid >> 5;
-    const int chunk = blockIdx.x, cblk = blockIdx.y, frame = blockIdx.z;
-    const int c0 = cblk * 256 + cx * 8;
-    float s[8], q[8];
+    const int tid = threadIdx.x;
+    const int chunk = blockIdx.x, frame = blockIdx.y;
+    const int CV = C >> 3;
+    const int cols = CV < 256 ? CV : 256;
+    const int rl = 256 / cols;                             // row lanes (threads beyond cols * rl idle)
+    const int cx = tid % cols, ry = tid / cols;
+    const int r0 = chunk * rows_per_chunk;
+    int r1 = r0 + rows_per_chunk;
+    r1 = r1 < HW ? r1 : HW;
+    const int cpg = C / 32;
+    if (tid < 32) { gS[tid] = 0.f; gQ[tid] = 0.f; }
+    for (int cv0 = 0; cv0 < CV; cv0 += 256) {              // (one pass unless C > 2048)
+        float s[8], q[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    if (c0 < C) {
-        const int r0 = chunk * rows_per_chunk;
-        int r1 = r0 + rows_per_chunk;
-        r1 = r1 < HW ? r1 : HW;
-        const f16* base = x + (size_t)frame * HW * ldx + c0;
-        for (int r = r0 + ry; r < r1; r += 8) {
-            const f16x8 a = *(const f16x8*)(base + (size_t)r * ldx);
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        const int cv = cv0 + cx;
+        if (ry < rl && cv < CV) {
+            const f16* base = x + (size_t)frame * HW * ldx + cv * 8;
+            int r = r0 + ry;
+            for (; r + 3 * rl < r1; r += 4 * rl) {         // 4 independent 16-byte loads in flight
+                f16x8 a[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float v = (float)a[e];
-                s[e] += v;
-                q[e] = fmaf(v, v, q[e]);
+                for (int u = 0; u < 4; ++u) a[u] = *(const f16x8*)(base + (size_t)(r + u * rl) * ldx);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (float)a[u][e];
+                        s[e] += v;
+                        q[e] = fmaf(v, v, q[e]);
+                    }
+            }
+            for (; r < r1; r += rl) {
+                const f16x8 a = *(const f16x8*)(base + (size_t)r * ldx);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (float)a[e];
+                    s[e] += v;
+                    q[e] = fmaf(v, v, q[e]);
+                }
             }
         }
+        __syncthreads();                                   // (previous pass's readers of sS / cS are done)
+        if (ry < rl) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sS[(ry * cols + cx) * 8 + e] = s[e]; sQ[(ry * cols + cx) * 8 + e] = q[e]; }
+        }
+        __syncthreads();
+        const int nch = cols * 8;                          // channels of this pass
+        for (int c = tid; c < nch; c += 256) {
+            float ts = 0.f, tq = 0.f;
+            for (int r = 0; r < rl; ++r) { ts += sS[r * nch + c]; tq += sQ[r * nch + c]; }
+            cS[c] = ts;
+            cQ[c] = tq;
+        }
+        __syncthreads();
+        if (tid < 32) {                                    // group tid: its channels that fall into this pass, in order
+            int ca = tid * cpg - cv0 * 8, cb = ca + cpg;
+            ca = ca < 0 ? 0 : ca;
+            cb = cb > nch ? nch : cb;
+            float a = 0.f, b = 0.f;
+            for (int c = ca; c < cb; ++c) { a += cS[c]; b += cQ[c]; }
+            gS[tid] += a;
+            gQ[tid] += b;
+        }
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { sS[ry][cx * 8 + e] = s[e]; sQ[ry][cx * 8 + e] = q[e]; }
-    if (tid < 32) { gS[tid] = 0.f; gQ[tid] = 0.f; }
-    __syncthreads();
-    float ts = 0.f, tq = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { ts += sS[r][tid]; tq += sQ[r][tid]; }
-    // channel -> group.  Done by ONE thread per group in channel order (deterministic).
-    sS[0][tid] = ts;
-    sQ[0][tid] = tq;
-    __syncthreads();
     if (tid < 32) {
-        const int cpg = C / 32;
-        const int g = tid;
-        int ca = g * cpg - cblk * 256, cb = ca + cpg;
-        ca = ca < 0 ? 0 : ca;
-        cb = cb > 256 ? 256 : cb;
-        float a = 0.f, b = 0.f;
-        for (int c = ca; c < cb; ++c) { a += sS[0][c]; b += sQ[0][c]; }
-        float* p = part + (((size_t)frame * nparts + (chunk * gridDim.y + cblk)) * 32 + g) * 2;
-        p[0] = a;
-        p[1] = b;
+        float* p = part + (((size_t)frame * nparts + chunk) * 32 + tid) * 2;
+        p[0] = gS[tid];
+        p[1] = gQ[tid];
     }
 }
 
 extern "C" int mofa_gn_partial_f16(const void* x, float* part, int nframes, int HW, int C, int ldx,
                                    mofa_stream_t stream) {
-    if (!x || !part || nframes <= 0 || HW <= 0 || C <= 0 || C % 32 != 0 || C % 8 != 0 || ldx % 8 != 0) return MOFA_EINVAL;
+    if (!x || !part || nframes <= 0 || HW <= 0 || C <= 0 || C % 32 != 0 || C % 8 != 0 || C > 4096 || ldx % 8 != 0) return MOFA_EINVAL;
     const int nch = gn_nchunks(HW);
-    int rpc = cdiv(HW, nch);
-    rpc = (rpc + 7) / 8 * 8;
-    const int ncb = cdiv(C, 256);
-    dim3 grid(nch, ncb, nframes);
-    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, part, HW, C, ldx, rpc,
-                       nch * ncb);
+    const int rpc = cdiv(HW, nch);
+    dim3 grid(nch, nframes);
+    hipLaunchKernelGGL(gn_partial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const f16*)x, part, HW, C, ldx, rpc, nch);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
@@ -238,6 +272,113 @@ extern "C" int mofa_affine_act_f16(const void* x, const float* scale, const floa
     nb = nb > 16384 ? 16384 : nb;
     hipLaunchKernelGGL(affine_act_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, (const f16*)x, scale, shift,
                        (f16*)y, nvec, HW, C, ldx, ldy, silu);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// ---- fused finalize + apply (single-rank path) ---------------------------------------------------------------------------
+// grid = (row chunks of a frame, frames).  Prologue: thread t sums partial value (group t >> 1, s / q = t & 1) ... 64 values
+// per partial entry, entries strided over the 4 quarter-workgroups, fp64, then a fixed-order combine of the 4 quarters.
+// The summation tree depends only on (fps, nparts): bit-identical run to run and across workgroups of one set.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ part,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       f16* __restrict__ y, int HW, int C, int ldx, int ldy, int fps, int nparts,
+                                                       int rows_per_wg, float eps, int silu) {
+    extern __shared__ __attribute__((aligned(16))) char gn_smem[];
+    float* sScale = (float*)gn_smem;                         // [C]
+    float* sShift = sScale + C;                              // [C]
+    __shared__ double dAcc[16][64];
+    __shared__ float sMean[32], sRstd[32];
+    const int tid = threadIdx.x, frame = blockIdx.y;
+    const int stat = frame / fps;
+    {
+        // 16 threads per entry (16 B = 2 groups x {s, q} each), 16 entries per sweep, 4 sweeps in flight
+        const int slot = tid & 15, el = tid >> 4;
+        const f32x4* p0 = (const f32x4*)(part + (size_t)stat * fps * nparts * 64) + slot;
+        const int total = fps * nparts;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        int i = el;
+        for (; i + 48 < total; i += 64) {
+            const f32x4 v0 = p0[(size_t)i * 16], v1 = p0[(size_t)(i + 16) * 16], v2 = p0[(size_t)(i + 32) * 16],
+                        v3 = p0[(size_t)(i + 48) * 16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += ((double)v0[k] + (double)v1[k]) + ((double)v2[k] + (double)v3[k]);
+        }
+        for (; i < total; i += 16) {
+            const f32x4 v = p0[(size_t)i * 16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += (double)v[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dAcc[el][slot * 4 + k] = a[k];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += dAcc[r][tid];
+        dAcc[0][tid] = t;                                    // (row 0 is read only by its own writer thread above)
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const double s = dAcc[0][2 * tid], q = dAcc[0][2 * tid + 1];
+        const double cnt = (double)fps * (double)HW * (double)(C / 32);
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        sMean[tid] = (float)mean;
+        sRstd[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / 32;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float sc = sRstd[g] * gamma[c];
+        sScale[c] = sc;
+        sShift[c] = beta[c] - sMean[g] * sc;
+    }
+    __syncthreads();
+    const int CV = C >> 3;
+    const int r0 = blockIdx.x * rows_per_wg;
+    int r1 = r0 + rows_per_wg;
+    r1 = r1 < HW ? r1 : HW;
+    const int nrows = r1 - r0;
+    const f16* xb = x + ((size_t)frame * HW + r0) * ldx;
+    f16* yb = y + ((size_t)frame * HW + r0) * ldy;
+    // (row, column vector) of this thread, advanced by 256 vectors per iteration without divisions
+    int row = tid / CV, cv = tid - row * CV;
+    const int drow = 256 / CV, dcv = 256 - drow * CV;
+    while (row < nrows) {
+        const f16x8 a = *(const f16x8*)(xb + (size_t)row * ldx + cv * 8);
+        const f32x4 s0 = *(const f32x4*)(sScale + cv * 8), s1 = *(const f32x4*)(sScale + cv * 8 + 4);
+        const f32x4 h0 = *(const f32x4*)(sShift + cv * 8), h1 = *(const f32x4*)(sShift + cv * 8 + 4);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = fmaf((float)a[e], e < 4 ? s0[e] : s1[e - 4], e < 4 ? h0[e] : h1[e - 4]);
+            if (silu) v = silu_f(v);
+            o[e] = (f16)v;
+        }
+        *(f16x8*)(yb + (size_t)row * ldy + cv * 8) = o;
+        cv += dcv;
+        row += drow;
+        if (cv >= CV) { cv -= CV; ++row; }
+    }
+}
+
+extern "C" int mofa_gn_apply_f16(const void* x, const float* part, const float* gamma, const float* beta, void* y, int nframes,
+                                 int HW, int C, int ldx, int ldy, int frames_per_stat, float eps, int silu,
+                                 mofa_stream_t stream) {
+    if (!x || !part || !gamma || !beta || !y || nframes <= 0 || HW <= 0 || frames_per_stat <= 0 ||
+        nframes % frames_per_stat != 0 || C % 32 != 0 || C % 8 != 0 || C > 8192 || ldx % 8 != 0 || ldy % 8 != 0)
+        return MOFA_EINVAL;
+    const int nparts = mofa_gn_nparts(HW, C);
+    // rows per workgroup: about 64 K elements each (16 vectors of 8 per thread), at least 2 workgroups per CU in total
+    int rpw = (65536 + C - 1) / C;
+    while (rpw > 16 && (long long)cdiv(HW, rpw) * nframes < 1024) rpw = (rpw + 1) / 2;
+    const int chunks = cdiv(HW, rpw);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, nframes), dim3(256), (size_t)C * 8, (hipStream_t)stream, (const f16*)x, part,
+                       gamma, beta, (f16*)y, HW, C, ldx, ldy, frames_per_stat, nparts, rpw, eps, silu);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

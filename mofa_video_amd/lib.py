@@ -43,6 +43,7 @@ PROTOTYPES = {
     "mofa_version": [],
     "mofa_igemm_f16": [C.POINTER(IgemmArgs), _P],
     "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
+    "mofa_attn_spatial_qb_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_attn_temporal_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_attn_temporal_masked_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint32, _P],
@@ -52,6 +53,7 @@ PROTOTYPES = {
     "mofa_gn_finalize": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "mofa_gn_reduce": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_gn_finalize_sums": [_P, _P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P],
+    "mofa_gn_apply_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "mofa_affine_act_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_layernorm_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     "mofa_axpby_f32": [_P, _P, _L, _F, _F, _P],

@@ -166,6 +166,9 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
 
 
 # ---- normalisation -------------------------------------------------------------------------------------
+GN_FUSED_MAX_ENTRIES = 512     # partial entries (256 B each) a statistics set may have for the two-launch GroupNorm
+
+
 def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None, reduce_fn=None,
                frames_total=None):
     """reduce_fn(sums fp64 [nstat,32,2]) -> all-reduced sums: used when the frames of a statistics set are sharded
@@ -176,10 +179,17 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
     assert x.shape[0] == nframes * HW
     nparts = lib.mofa_gn_nparts(HW, Cc)
     part = torch.empty((nframes, nparts, 32, 2), dtype=F32, device=x.device)
-    scale = torch.empty((nframes, Cc), dtype=F32, device=x.device)
-    shift = torch.empty((nframes, Cc), dtype=F32, device=x.device)
     st = L.stream_ptr()
     L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part), nframes, HW, Cc, _ld(x), st), "mofa_gn_partial_f16")
+    if out is None:
+        out = torch.empty((x.shape[0], Cc), dtype=F16, device=x.device)
+    if reduce_fn is None and frames_per_stat * nparts <= GN_FUSED_MAX_ENTRIES:
+        # two launches: the applying kernel combines the partial sums of its statistics set itself
+        L.check(lib.mofa_gn_apply_f16(L.ptr(x), L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(out), nframes, HW, Cc, _ld(x),
+                                      _ld(out), frames_per_stat, eps, 1 if silu else 0, st), "mofa_gn_apply_f16")
+        return out
+    scale = torch.empty((nframes, Cc), dtype=F32, device=x.device)
+    shift = torch.empty((nframes, Cc), dtype=F32, device=x.device)
     if reduce_fn is None:
         L.check(lib.mofa_gn_finalize(L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes, HW,
                                      Cc, frames_per_stat, eps, st), "mofa_gn_finalize")
@@ -191,8 +201,6 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
         cnt = float(frames_total) * HW * (Cc // 32)
         L.check(lib.mofa_gn_finalize_sums(L.ptr(sums), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes,
                                           Cc, frames_per_stat, cnt, eps, L.stream_ptr()), "mofa_gn_finalize_sums")
-    if out is None:
-        out = torch.empty((x.shape[0], Cc), dtype=F16, device=x.device)
     L.check(lib.mofa_affine_act_f16(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), nframes, HW, Cc, _ld(x), _ld(out),
                                     1 if silu else 0, st), "mofa_affine_act_f16")
     return out
@@ -213,9 +221,10 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
 Q_FOLD_LOG2E = 1.4426950408889634
 
 
-def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, prescaled=False):
+def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, prescaled=False, query_blocks=0):
     """q/k/v: [nframes*S, heads*head_dim] column blocks (views allowed); scale defaults to head_dim**-0.5.
-    prescaled: q already holds Q * head_dim**-0.5 * log2(e) (the constant folded into the Q projection weights)."""
+    prescaled: q already holds Q * head_dim**-0.5 * log2(e) (the constant folded into the Q projection weights).
+    query_blocks: 0 = the launcher's rule, 1 / 2 = force 128- / 256-row workgroups (parity tests)."""
     lib = L.load()
     Cc = heads * head_dim
     scale = -1.0 if prescaled else (head_dim ** -0.5 if scale is None else scale)
@@ -223,8 +232,8 @@ def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, 
     if out is None:
         out = torch.empty((nframes * S, Cc), dtype=F16, device=q.device)
     t0 = TIMER.start() if TIMER is not None else None
-    L.check(lib.mofa_attn_spatial_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nframes, heads, head_dim, S, _ld(q),
-                                      _ld(k), _ld(v), _ld(out), scale, st), "mofa_attn_spatial_f16")
+    L.check(lib.mofa_attn_spatial_qb_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nframes, heads, head_dim, S, _ld(q),
+                                         _ld(k), _ld(v), _ld(out), scale, int(query_blocks), st), "mofa_attn_spatial_qb_f16")
     if t0 is not None:
         TIMER.stop("attn_spatial_kernel", t0, flops=4.0 * S * S * Cc * nframes)
     return out

@@ -185,6 +185,12 @@ class SpatioTemporalResBlock(nn.Module):
 # ----------------------------------------------------------------------------
 # attention (diffusers/models/attention.py, attention_processor.py)
 # ----------------------------------------------------------------------------
+# softmax(q k^T / sqrt(d)) v.  A module-level hook so that tests which run this oracle on the GPU at the full 576x1024
+# geometry (S = 9216 keys per frame: the materialised fp32 scores of all 50 frames are 85 GB) can substitute an
+# exact batch-chunked evaluation of the same formula (tests/test_fullgeom_gpu.py).
+SDPA = F.scaled_dot_product_attention
+
+
 class Attention(nn.Module):
     def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, bias=False,
                  norm_num_groups=None, eps=1e-5, residual_connection=False):
@@ -215,7 +221,7 @@ class Attention(nn.Module):
         q = q.view(B, -1, self.heads, d).transpose(1, 2)
         k = k.view(B, -1, self.heads, d).transpose(1, 2)
         v = v.view(B, -1, self.heads, d).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v)
+        o = SDPA(q, k, v)
         o = o.transpose(1, 2).reshape(B, -1, inner)
         o = self.to_out[0](o)
         if input_ndim == 4:

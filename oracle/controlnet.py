@@ -146,9 +146,9 @@ class FlowControlNet(nn.Module):
     def embed_time(self, sample, timestep, added_time_ids):
         timesteps = timestep
         if not torch.is_tensor(timesteps):
-            timesteps = torch.tensor([timesteps], dtype=torch.float64)
+            timesteps = torch.tensor([timesteps], dtype=torch.float64, device=sample.device)
         elif timesteps.ndim == 0:
-            timesteps = timesteps[None]
+            timesteps = timesteps[None].to(sample.device)
         batch_size = sample.shape[0]
         timesteps = timesteps.expand(batch_size)
         emb = self.time_embedding(self.time_proj(timesteps).to(sample.dtype))
@@ -165,7 +165,7 @@ class FlowControlNet(nn.Module):
         encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_frames, dim=0)
         sample = self.conv_in(sample)                                                # :294
         warped = self.warped_cond_features(controlnet_cond, controlnet_flow)
-        image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype)
+        image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
 
         count, length = 0, len(warped)
         sample = sample + warped[count]                                              # :328

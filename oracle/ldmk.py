@@ -142,7 +142,7 @@ class LandmarkFlowControlNet(FlowControlNet):
             s = F.interpolate(ldmk, scale_factor=1 / scale)
             scale_landmarks[s.shape[-2]] = s
         warped, occlusion_masks = self.warped_cond_features(controlnet_cond, controlnet_flow)
-        image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype)
+        image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
         count, length = 0, len(warped)
         sample = sample + warped[count] + scale_landmarks[sample.shape[-2]]           # :474
         count += 1

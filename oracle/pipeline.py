@@ -8,9 +8,9 @@ import torch
 from .vae import decode_latents
 
 
-def make_added_time_ids(dtype=torch.float32):
+def make_added_time_ids(dtype=torch.float32, device=None):
     """pipeline.py:430-440 -- overwritten to fps=6, motion_bucket_id=128, noise_aug=0.02, x2 for CFG."""
-    ids = torch.tensor([[6, 128, 0.02]], dtype=dtype)
+    ids = torch.tensor([[6, 128, 0.02]], dtype=dtype, device=device)
     return torch.cat([ids] * 2)
 
 
@@ -29,8 +29,8 @@ def denoise(unet, controlnet, scheduler, latents, image_latents, image_embedding
     controlnet_condition = torch.cat([controlnet_condition] * 2)                  # :393
     controlnet_flow = torch.cat([controlnet_flow] * 2)                            # :396
     guidance_scale = torch.linspace(min_guidance_scale, max_guidance_scale, num_frames).unsqueeze(0)
-    guidance_scale = guidance_scale.to(latents.dtype)[(...,) + (None,) * 3]       # :423-426
-    added_time_ids = make_added_time_ids(latents.dtype)
+    guidance_scale = guidance_scale.to(latents.device, latents.dtype)[(...,) + (None,) * 3]       # :423-426
+    added_time_ids = make_added_time_ids(latents.dtype, latents.device)
     trace = []
     for t in timesteps:                                                           # :447-511
         latent_model_input = torch.cat([latents] * 2)
@@ -78,8 +78,8 @@ def denoise_hybrid(unet, face_controlnet, drag_controlnet, scheduler, latents, i
     drag_flow = torch.cat([drag_flow] * 2)
     landmarks = torch.cat([landmarks] * 2)
     guidance_scale = torch.linspace(min_guidance_scale, max_guidance_scale, num_frames).unsqueeze(0)
-    guidance_scale = guidance_scale.to(latents.dtype)[(...,) + (None,) * 3]
-    added_time_ids = make_added_time_ids(latents.dtype)
+    guidance_scale = guidance_scale.to(latents.device, latents.dtype)[(...,) + (None,) * 3]
+    added_time_ids = make_added_time_ids(latents.dtype, latents.device)
     for t in timesteps:
         x = torch.cat([latents] * 2)
         x = scheduler.scale_model_input(x, t)
@@ -137,8 +137,8 @@ def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, i
     if drag_controlnet is not None:
         drag_flow = torch.cat([drag_flow] * 2)
     guidance_scale = torch.linspace(min_guidance_scale, max_guidance_scale, window_size).unsqueeze(0)
-    guidance_scale = guidance_scale.to(latents.dtype)[(...,) + (None,) * 3]
-    added_time_ids = make_added_time_ids(latents.dtype)
+    guidance_scale = guidance_scale.to(latents.device, latents.dtype)[(...,) + (None,) * 3]
+    added_time_ids = make_added_time_ids(latents.dtype, latents.device)
     views = window_views(num_frames, window_size, stride)
     count = torch.zeros_like(latents)
     value = torch.zeros_like(latents)

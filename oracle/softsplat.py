@@ -16,9 +16,10 @@ def softsplat_sum(tenIn: torch.Tensor, tenFlow: torch.Tensor) -> torch.Tensor:
     tenFlow = tenFlow.float().contiguous()
     N, C, H, W = tenIn.shape
     assert tenFlow.shape == (N, 2, H, W)
-    out = torch.zeros(N, C, H * W, dtype=torch.float32)
-    gx = torch.arange(W, dtype=torch.float32).view(1, 1, W).expand(N, H, W)
-    gy = torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(N, H, W)
+    dev = tenIn.device
+    out = torch.zeros(N, C, H * W, dtype=torch.float32, device=dev)
+    gx = torch.arange(W, dtype=torch.float32, device=dev).view(1, 1, W).expand(N, H, W)
+    gy = torch.arange(H, dtype=torch.float32, device=dev).view(1, H, 1).expand(N, H, W)
     fx = gx + tenFlow[:, 0]                       # :298
     fy = gy + tenFlow[:, 1]                       # :299
     finite = torch.isfinite(fx) & torch.isfinite(fy)   # :301-302

@@ -74,9 +74,9 @@ class UNetSpatioTemporalConditionControlNetModel(nn.Module):
         """:386-417 -- time + added-time-id embeddings, [batch, 1280]."""
         timesteps = timestep
         if not torch.is_tensor(timesteps):
-            timesteps = torch.tensor([timesteps], dtype=torch.float64)
+            timesteps = torch.tensor([timesteps], dtype=torch.float64, device=sample.device)
         elif timesteps.ndim == 0:
-            timesteps = timesteps[None]
+            timesteps = timesteps[None].to(sample.device)
         batch_size = sample.shape[0]
         timesteps = timesteps.expand(batch_size)
         emb = self.time_embedding(self.time_proj(timesteps).to(sample.dtype))
@@ -91,7 +91,7 @@ class UNetSpatioTemporalConditionControlNetModel(nn.Module):
         emb = emb.repeat_interleave(num_frames, dim=0)                           # :424
         encoder_hidden_states = encoder_hidden_states.repeat_interleave(num_frames, dim=0)  # :426
         sample = self.conv_in(sample)                                            # :429
-        image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype)
+        image_only_indicator = torch.zeros(batch_size, num_frames, dtype=sample.dtype, device=sample.device)
 
         down_block_res_samples = (sample,)
         for blk in self.down_blocks:                                             # :434-459

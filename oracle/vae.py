@@ -169,7 +169,7 @@ class AutoencoderKLTemporalDecoder(nn.Module):
 
     def decode(self, z, num_frames=1):
         batch_size = z.shape[0] // num_frames
-        ioi = torch.zeros(batch_size, num_frames, dtype=z.dtype)
+        ioi = torch.zeros(batch_size, num_frames, dtype=z.dtype, device=z.device)
         return self.decoder(z, num_frames=num_frames, image_only_indicator=ioi)
 
 

@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu():
     a = lib.IgemmArgs()
     assert l.mofa_igemm_f16(ctypes.byref(a), None) == -22          # null pointers
     assert l.mofa_attn_spatial_f16(None, None, None, None, 1, 1, 64, 8, 8, 8, 8, 8, 0.125, None) == -22
-    assert l.mofa_gn_nparts(9216, 320) == 36 * 2
+    assert l.mofa_gn_nparts(9216, 320) == 16 and l.mofa_gn_nparts(576, 1280) == 4
     assert l.mofa_softsplat_ws_bytes(24, 72, 128) > 24 * 72 * 128 * 44
 
 

@@ -167,7 +167,7 @@ def test_attn_spatial_online_softmax_rescale(ops):
 
 @pytest.mark.parametrize("hd,qb", [(64, 1), (64, 2), (128, 1)])
 @pytest.mark.parametrize("pattern", ["rising", "falling", "spikes"])
-def test_attn_spatial_reference_moves(ops, hd, qb, pattern, monkeypatch):
+def test_attn_spatial_reference_moves(ops, hd, qb, pattern):
     """The kernel exponentiates scores relative to a REFERENCE that is only moved when a key tile's probabilities near the
     fp16 range.  Logits spanning hundreds of units: rising along the keys (the reference must move tile after tile, each
     time rescaling O and l), falling (everything after the first tiles underflows to 0 exactly as in the reference), and
@@ -189,7 +189,7 @@ def test_attn_spatial_reference_moves(ops, hd, qb, pattern, monkeypatch):
     k = k * gain[:, None]
     qkv = torch.cat([q, k, v], 1).half()
     d = qkv.to(DEV)
-    out = ops.attn_spatial(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S, head_dim=hd)
+    out = ops.attn_spatial(d[:, :Cc], d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S, head_dim=hd, query_blocks=qb)
     qf, kf, vf = [t.float().reshape(frames, S, heads, hd).transpose(1, 2) for t in d.split(Cc, dim=1)]   # fp32, on the GPU
     ref, top = [], 0.0
     for f0 in range(0, frames, 8):
@@ -201,7 +201,7 @@ def test_attn_spatial_reference_moves(ops, hd, qb, pattern, monkeypatch):
     # the production form: head_dim^-0.5 * log2(e) folded into Q before its (single) fp16 rounding, 1.5 x the logits
     from mofa_video_amd.ops import Q_FOLD_LOG2E
     qs = (d[:, :Cc].float() * 1.5 * (hd ** -0.5 * Q_FOLD_LOG2E)).half()
-    out = ops.attn_spatial(qs, d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S, head_dim=hd, prescaled=True)
+    out = ops.attn_spatial(qs, d[:, Cc:2 * Cc], d[:, 2 * Cc:], frames, heads, S, head_dim=hd, prescaled=True, query_blocks=qb)
     qf = qs.float().reshape(frames, S, heads, hd).transpose(1, 2)
     ref, top = [], 0.0
     for f0 in range(0, frames, 8):

@@ -1,6 +1,6 @@
 """Spatial-attention kernel timing on the denoise step's shapes (25 f x CFG 2 = 50 frames; L0 S = 9216 / 5 heads,
 L1 S = 2304 / 10 heads), random data, HIP-event timed, plus an output checksum so that two builds / environment switches
-(MOFA_ATTN_PIPE=0|1, MOFA_ATTN_QB=1|2) can be compared for bit identity from separate processes.
+(--qb 1|2 forces the workgroup size) can be compared for bit identity from separate processes.
 
     python tools/attn_bench.py [--iters 5]
 """
@@ -18,13 +18,14 @@ from mofa_video_amd import lib, ops  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--qb", type=int, default=0, help="0 = the launcher's rule, 1 / 2 = 128- / 256-row workgroups")
     args = ap.parse_args()
     lib.load()
     torch.manual_seed(0)
     for (fr, heads, S, tag) in [(50, 5, 9216, "L0"), (50, 10, 2304, "L1"), (50, 5, 9216 - 40, "L0 ragged"), (4, 5, 1000, "small ragged")]:
         Cc = heads * 64
         qkv = (torch.randn(fr * S, 3 * Cc, device="cuda")).half()
-        run = lambda: ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], fr, heads, S)   # noqa: E731
+        run = lambda: ops.attn_spatial(qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:], fr, heads, S, query_blocks=args.qb)   # noqa: E731
         out = run()
         torch.cuda.synchronize()
         ts = []
