@@ -84,7 +84,7 @@ enum { MOFA_PAD_SAME = 0, MOFA_PAD_TRAILING = 1 };
 /* output tiles of the implicit GEMM: 4 waves / 2 workgroups per CU (128x128, 192x128) and the 8-wave phase-pipelined
  * 256x256 tile (needs 16-byte aligned rows and no activation on residual kinds: MOFA_EINVAL if forced on an ineligible
  * call) */
-enum { MOFA_TILE_AUTO = 0, MOFA_TILE_128X128 = 2, MOFA_TILE_192X128 = 4, MOFA_TILE_256X256 = 5 };
+enum { MOFA_TILE_AUTO = 0, MOFA_TILE_128X128 = 2, MOFA_TILE_192X128 = 4, MOFA_TILE_256X256 = 5, MOFA_TILE_256X320 = 6 };
 
 int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
 

@@ -496,14 +496,15 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
             for (igemm_kern_t k : c.k)
                 if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, c.lds) != hipSuccess)
                     return MOFA_ELAUNCH;
-        if (igemm8_init() != MOFA_OK) return MOFA_ELAUNCH;
+        if (igemm8_init() != MOFA_OK || igemm320_init() != MOFA_OK) return MOFA_ELAUNCH;
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
             n_cu = cus;
         ready = true;
     }
-    if (a->tile != 0 && a->tile != MOFA_TILE_128X128 && a->tile != MOFA_TILE_192X128 && a->tile != MOFA_TILE_256X256)
+    if (a->tile != 0 && a->tile != MOFA_TILE_128X128 && a->tile != MOFA_TILE_192X128 && a->tile != MOFA_TILE_256X256 &&
+        a->tile != MOFA_TILE_256X320)
         return MOFA_EINVAL;
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
     const long long Ktot = (long long)taps * a->Cin;
@@ -537,8 +538,22 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         {
             const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 256);
             const double cost = (double)((t + n_cu - 1) / n_cu) * 256 * 256 * 0.62 * (1.0 + epi8[kind] / nk);
-            if (cost < best) choice = MOFA_TILE_256X256;
+            if (cost < best) { best = cost; choice = MOFA_TILE_256X256; }
         }
+        if (kind != 8) {
+            // 256x320 (igemm320.hip): 0.58 per area (10 % less LDS-DMA, 7 % fewer fragment reads per flop than 256x256); its
+            // epilogues move 25 % more outputs per tile through a smaller scratch
+            static const double epi320[8] = {3.0, 10.0, 10.0, 11.5, 3.5, 10.5, 10.5, 12.0};   // fitted: profiles/r03_igemm_tiles_bench.log
+            const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 320);
+            const double cost = (double)((t + n_cu - 1) / n_cu) * 256 * 320 * 0.58 * (1.0 + epi320[kind] / nk);
+            if (cost < best) { best = cost; choice = MOFA_TILE_256X320; }
+        }
+    }
+    if (choice == MOFA_TILE_256X320) {
+        const int rc = igemm320_launch(a, kind, n_cu, (hipStream_t)stream);
+        if (rc <= 0) return rc;                               // launched (0) or failed (< 0)
+        if (a->tile == MOFA_TILE_256X320) return MOFA_EINVAL; // explicitly requested but not eligible
+        choice = MOFA_TILE_256X256;                           // chosen by the model but not eligible: next best pipeline tile
     }
     if (choice == MOFA_TILE_256X256) {
         const int rc = igemm8_launch(a, kind, n_cu, (hipStream_t)stream);

@@ -1,0 +1,467 @@
+// Implicit GEMM, 256 (M) x 320 (N) output tile, 8 waves, phase-pipelined K loop: the tile of the UNet's channel counts.
+//
+// Every N of the SVD UNet / ControlNet trunk is a multiple of 320 (320, 640, 960, 1280, 1920, 2560, 3840, ...): a
+// 320-wide tile has NO padded columns on any of them (256-wide tiles waste 37.5 % of their MFMA issue at N = 320, 17 % at
+// N = 640), reads the activation tile ONCE where N = 320 (the 256x256 and 192x128 kernels stream it 2 and 3 times), and
+// moves 10 % fewer bytes through the LDS-DMA path per flop than the 256x256 tile ((256 + 320) / (256 * 320) rows per
+// output).  Same contract (mofa_hip.h), operand roles (MFMA A = weight tile, B = activation tile: an accumulator lane owns
+// one output row), buffer-descriptor DMA with bounds-check zero fill, persistent XCD-aware tile walk and two-wave-group
+// stagger as igemm8.hip; what differs:
+//
+//   * wave (wm, wn) of 4 x 2 owns 64 (M) x 160 (N) outputs = 2 x 5 accumulator tiles of 32x32 (160 accumulator registers).
+//     A K tile (64 deep) is consumed in TWO PHASES BY K HALVES: phase p multiplies K columns [32 p, 32 p + 32) of all the
+//     wave's rows -- 4 X + 10 W fragment reads (56 registers), 20 MFMAs (640 matrix-pipe cycles) -- so both phases carry
+//     the same reads and the same MFMA count (the 256x256 kernel splits by X rows: 16 + 8 reads).
+//   * LDS: a ring of 2 K tiles, each as two K-HALF PLANES [X 256 rows | W 320 rows] x 64 B (36 KB per plane, 72 KB per K
+//     tile, 144 KB ring + 8 x 2 KB wave scratch = the CU's 160 KB).  A plane is released when its phase's fragments are in
+//     registers and refilled in the NEXT phase: phase 0 issues plane 1 of K tile t + 1, phase 1 issues plane 0 of K tile
+//     t + 2 -- 4 or 5 DMA pieces per wave and phase (9 per K tile; waves 0-3 take the ring's 4 odd W pieces in plane 0,
+//     waves 4-7 in plane 1), each with one K tile of flight before the counted wait `vmcnt(9)`.  A DMA piece is 16 rows x
+//     64 B (tools/dmabench.hip, profiles/r03_dmabench.log: up to 5 such half-line pieces per phase hide completely behind
+//     20 MFMAs of the partner wave; 6 do not).  64-byte rows: the 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3)
+//     (applied to the DMA source address and to the fragment read; tools/lds_bank_sim.py: conflict-free).
+//   * bias (and the row vector when the wave's 64 rows share one row of it: every tile that does not straddle a frame) is
+//     the INITIAL VALUE of the accumulators, loaded straight into them at tile start -- no bias handling in any epilogue,
+//     no scratch image of it (the 2 KB scratch is one 32 x 32 fp16 / 16 x 32 fp32 transpose).
+//   * epilogues: no residual, uniform row vector -> activation in the fragment layout, fp16, 32 x 32 transposes, 16-byte
+//     stores; residuals / per-row row vector -> 16 x 32 fp32 transposes (half the lanes write at a time), the sum rounded once.
+// Kinds: plain (+ SiLU / ReLU / GELU), row vector, one or two residuals (the GEGLU pair kind stays on the 256x256 kernel).
+#include "igemm_common.h"
+#include "igemm_pipe.h"
+
+namespace {
+
+constexpr int WN3 = 2, MI3 = 2, NJ3 = 5;                       // wave grid 4 x 2, accumulator tiles per wave
+constexpr int TBM3 = 256, TBN3 = 320;
+constexpr int RBH = 64;                                        // bytes of one K half of a row
+constexpr int XPL = TBM3 * RBH;                                // X part of a plane (16 KB)
+constexpr int PLANE = (TBM3 + TBN3) * RBH;                     // 36 KB
+constexpr int SLOT = 2 * PLANE;                                // one K tile: 72 KB
+constexpr int LDS3_BYTES = 2 * SLOT;                           // 147456 (the epilogue transposes through a free ring plane)
+constexpr int LOOKAHEAD3 = 9;                                  // DMA instructions of the last two phases may be in flight
+
+struct Cursor3 {                    // one K-half plane of the persistent K-tile stream
+    int local;                      // walk position of the output tile it is in
+    int ikc, ksw, ky, kx;           // K tile within the tap / overall, tap coordinates (convT3: ky = tap)
+    int gx0, gx1;                   // packed row geometry of this wave's two X pieces (16 rows each)
+    unsigned xo0, xo1;              // source row of the current tap + this lane's swizzled chunk, bytes from aux.xbase
+    unsigned wo0;                   // weight row of W piece `wave` + this lane's swizzled chunk, bytes from a.w; the
+                                    // wave's other pieces are a uniform number of rows further (rows beyond N: out of the
+                                    // descriptor's range = zeros, no clamp)
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_args a, const int tilesN, const int ntiles,
+                                                              const Aux aux) {
+    constexpr bool R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0, RV = (EPI & EPI_RV) != 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY shared object
+    TileWalk walk;
+    walk.init(ntiles);
+    if (walk.local >= walk.count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;                                     // waves w and w + 4 share a SIMD
+    const int wm = wave / WN3, wn = wave - wm * WN3;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int taps = igemm_taps(a);
+    const int kpt = a.Cin / 64, nk = taps * kpt;
+    const size_t Ktot = (size_t)taps * a.Cin;
+
+    // ---- producer side ----------------------------------------------------------------------------------------------
+    // plane p of a K tile = 16 X pieces + 20 W pieces of 16 rows x 64 B; wave w issues X pieces w, w + 8, W pieces w, w + 8
+    // and, when p == grp, W piece 16 + (w & 3).  Lane l of a piece: row l / 4, slot l % 4 <- source chunk slot ^ ((row >> 2) & 3)
+    // = slot ^ ((l >> 4) & 3) (piece rows start at multiples of 16)
+    auto lane_now = [&]() __attribute__((always_inline)) { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    auto swz_bytes = [&](int l, int p) __attribute__((always_inline)) { return (((l & 3) ^ ((l >> 4) & 3)) * 16 + p * RBH); };
+    const int ks_ = a.ksize > 0 ? a.ksize : 3, dil_ = a.dil > 0 ? a.dil : 1;
+    const int org_ = a.pad == MOFA_PAD_TRAILING ? 0 : (ks_ >> 1);
+    auto pack_geo = [&](int m) __attribute__((always_inline)) -> int {
+        int g = m;
+        if (a.mode == MOFA_MODE_CONV3X3) {
+            const int img = fdiv(m, aux.hw), rem = m - img * (a.Hout * a.Wout);
+            const int oy = fdiv(rem, aux.wout);
+            g = (img << 20) | (oy << 10) | (rem - oy * a.Wout);
+        } else if (a.mode == MOFA_MODE_CONVT3) {
+            int lo = 1, hi = 1;
+            if (a.T > 0) {
+                const int fr = fdiv(m, aux.t3hw);
+                const int f = fr - fdiv(fr, aux.t3t) * a.T;
+                lo = f > 0; hi = f < a.T - 1;
+            }
+            g = m | (lo << 29) | (hi << 30);
+        }
+        return m < a.M ? g : -1;
+    };
+    // W pieces w + 8 and 16 + (w & 3) start 128 and 256 + 16 (w & 3) - 16 w rows after piece w (uniform byte distances)
+    const unsigned wd1 = 128u * (unsigned)(Ktot * 2), wd2 = (unsigned)(256 + 16 * (wave & 3) - 16 * wave) * (unsigned)(Ktot * 2);
+    constexpr unsigned W_DEAD = 0x80000000u;                       // past the end of the walk: beyond any weight tensor (< 2 GB)
+    const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)aux.xbase, 0, aux.x_bytes, 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, aux.w_bytes, 0x00020000);
+    auto bglds16 = [&](const decltype(rsx)& rs, unsigned voff, int soff, char* lds_wave_base) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+    };
+    auto tap_src = [&](int g, int ky, int kx, int swzb) __attribute__((always_inline)) -> unsigned {   // bytes from aux.xbase
+        int row = g;
+        bool ok = g >= 0;
+        if (a.mode == MOFA_MODE_CONV3X3) {
+            const int vy = ((g >> 10) & 1023) * a.stride + (ky - org_) * dil_;
+            const int vx = (g & 1023) * a.stride + (kx - org_) * dil_;
+            ok = ok && vy >= 0 && vx >= 0 && vy < a.Hin * a.up && vx < a.Win * a.up;
+            const int iy = (a.up == 2) ? (vy >> 1) : vy, ix = (a.up == 2) ? (vx >> 1) : vx;
+            row = ((g >> 20) * a.Hin + iy) * a.Win + ix;
+        } else if (a.mode == MOFA_MODE_CONVT3) {
+            ok = ok && !(ky == 0 && !((g >> 29) & 1)) && !(ky == 2 && !((g >> 30) & 1));
+            row = (g & 0x1fffffff) + (ky - 1) * a.HW + aux.row_shift;
+        }
+        const unsigned off = (unsigned)row * (unsigned)aux.ldxb + (unsigned)swzb;
+        return ok ? off : XO_INVALID;
+    };
+    auto cur_setup = [&](Cursor3& c, const int p) __attribute__((always_inline)) {
+        // branch-free on purpose (selects on the uniform `live`; see igemm8.hip)
+        const bool live = c.local < walk.count;
+        const int tile = walk.start + (live ? c.local : 0);
+        const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
+        const int l = lane_now(), r_l = l >> 2;
+        const int g0 = pack_geo(tm * TBM3 + 16 * wave + r_l), g1 = pack_geo(tm * TBM3 + 16 * (wave + 8) + r_l);
+        c.gx0 = live ? g0 : -1;
+        c.gx1 = live ? g1 : -1;
+        const unsigned wo = (unsigned)(tn * TBN3 + 16 * wave + r_l) * (unsigned)(Ktot * 2) + swz_bytes(l, p);
+        c.wo0 = live ? wo : W_DEAD;
+        c.ikc = 0; c.ksw = 0; c.ky = 0; c.kx = 0;
+    };
+    auto issue = [&](Cursor3& c, const int p, const int slot) __attribute__((always_inline)) {
+        if (c.ikc == 0) {
+            const int l = lane_now();
+            c.xo0 = tap_src(c.gx0, c.ky, c.kx, swz_bytes(l, p));
+            c.xo1 = tap_src(c.gx1, c.ky, c.kx, swz_bytes(l, p));
+        }
+        char* pl = smem + slot + p * PLANE;
+        bglds16(rsx, c.xo0, c.ikc * 128, pl + wave * 1024);
+        bglds16(rsx, c.xo1, c.ikc * 128, pl + (wave + 8) * 1024);
+        bglds16(rsw, c.wo0, c.ksw * 128, pl + XPL + wave * 1024);
+        bglds16(rsw, c.wo0 + wd1, c.ksw * 128, pl + XPL + (wave + 8) * 1024);
+        if (grp == p) bglds16(rsw, c.wo0 + wd2, c.ksw * 128, pl + XPL + (16 + (wave & 3)) * 1024);
+    };
+    auto advance = [&](Cursor3& c, const int p) __attribute__((always_inline)) {
+        ++c.ksw;
+        if (++c.ikc == kpt) {
+            c.ikc = 0;
+            if (a.mode == MOFA_MODE_CONV3X3) { if (++c.kx == ks_) { c.kx = 0; ++c.ky; } } else ++c.ky;
+        }
+        if (c.ksw == nk) { c.local += walk.stride; cur_setup(c, p); }
+    };
+
+    // ---- consumer side ----------------------------------------------------------------------------------------------
+    // fragment read addresses of ring slot 0, plane 0 (one register per 16-deep K step of a plane; accumulator tile and
+    // plane are immediates, the ring slot is added / subtracted per K tile)
+    // (the second 16-deep K step of a plane is the chunk with bit 1 flipped: address ^ 32)
+    int xa, wa;
+    {
+        const int sl = (lh ^ ((l31 >> 2) & 3)) * 16;
+        xa = (wm * MI3 * 32 + l31) * RBH + sl;
+        wa = XPL + (wn * NJ3 * 32 + l31) * RBH + sl;
+    }
+
+    Cursor3 ca, cb;                                                // plane 0 stream, plane 1 stream
+    ca.local = cb.local = walk.local;
+    cur_setup(ca, 0);
+    cur_setup(cb, 1);
+    // prologue: K tile 0 complete, plane 0 of K tile 1
+    issue(ca, 0, 0); advance(ca, 0);
+    issue(cb, 1, 0); advance(cb, 1);
+    issue(ca, 0, SLOT); advance(ca, 0);
+    wait_vmcnt_only<LOOKAHEAD3>();                                 // plane 0 of K tile 0 has landed
+    __builtin_amdgcn_s_barrier();
+
+    f32x16 acc[MI3][NJ3];
+    f16x8 xf[MI3][2], wf[NJ3][2];
+    auto phase = [&](auto pc, const int bo, const int bn) __attribute__((always_inline)) {
+        constexpr int P = decltype(pc)::v;                         // K half
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int xk = k2 ? (xa ^ 32) : xa, wk = k2 ? (wa ^ 32) : wa;
+#pragma unroll
+            for (int i = 0; i < MI3; ++i) xf[i][k2] = *(const f16x8*)(smem + xk + P * PLANE + i * 32 * RBH);
+#pragma unroll
+            for (int j = 0; j < NJ3; ++j) wf[j][k2] = *(const f16x8*)(smem + wk + P * PLANE + j * 32 * RBH);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 0) { issue(cb, 1, bn); advance(cb, 1); }   // plane 1 of the next K tile
+        else { issue(ca, 0, bo); advance(ca, 0); }                    // plane 0 of the K tile after it (this slot)
+        // DMA older than the last two phases has landed (read from the next phase on); this phase's fragment reads have
+        // returned BEFORE the barrier, so their plane may be refilled from the next phase on
+        wait_vmcnt<LOOKAHEAD3>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int i = 0; i < MI3; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[j][k2], xf[i][k2], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- epilogue scratch: the ring plane that is FREE while an epilogue runs ---------------------------------------------
+    // When a tile's K loop ends, the ring holds the next tile's K tile 0 (other slot, both planes) and plane 0 of its K tile 1
+    // (this slot); plane 1 of the last K tile's slot was read for the last time in the final phase and is refilled only by
+    // phase 0 of the NEXT tile -- by every wave into its own pieces.  Each wave therefore transposes through the four 1 KB
+    // blocks it will DMA into itself (X pieces w, w + 8 and W pieces w, w + 8 of that plane: 8 KB apart): 32 rows x 128 B,
+    // rows 8 b .. 8 b + 7 in block b.  No other wave touches those blocks before its fragment reads two barriers later, the
+    // wave's own DMA is issued after its epilogue (program order, lgkmcnt(0) at the end), and no barrier is needed.
+    auto srow = [&](int r) __attribute__((always_inline)) { return (r >> 3) * 8192 + (r & 7) * 128; };
+    auto act_apply = [&](auto ac, float v) __attribute__((always_inline)) -> float {
+        constexpr int ACT = decltype(ac)::v;
+        if constexpr (ACT == MOFA_ACT_SILU) return silu_f(v);
+        else if constexpr (ACT == MOFA_ACT_RELU) return fmaxf(v, 0.0f);
+        else if constexpr (ACT == MOFA_ACT_GELU) return gelu_erf_f(v);
+        else return v;
+    };
+    // register r of accumulator tile (i, j) is row 32 i + l31, column 32 j + 8 (r >> 2) + 4 lh + (r & 3)
+    // ---- no residual, no per-row vector: activation in the fragment layout, fp16; two accumulator tiles (64 columns) per
+    //      transpose so that a store instruction covers 8 whole 128-byte rows.  The wave's 160 columns start at byte 0 (wn = 0)
+    //      or 320 (wn = 1) of a 640-byte-aligned row: the pairs are (0,1) (2,3) + tile 4, or tile 0 + (1,2) (3,4), so that
+    //      every pair starts on a 128-byte boundary -----------------------------------------------------------------------------
+    auto epilogue_light = [&](auto ac, auto wnc, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(wnc)::v ? 1 : 0;              // first tile of the first pair; the single tile is 4 - 4 * J0... (0 or 4)
+        constexpr int JS = decltype(wnc)::v ? 0 : 4;
+        const int lane_e = lane_now();                             // (lane-derived offsets are not kept live across the K loop)
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
+        f16* out = (f16*)a.out;
+        float saccv = a.s_acc;                                     // VGPR operand on purpose (see igemm.hip's epilogue)
+        asm volatile("" : "+v"(saccv));
+        char* wr = eb + srow(l31);
+        const int wsw = (l31 >> 1) & 7, wpar = l31 & 1;
+#pragma unroll
+        for (int i = 0; i < MI3; ++i) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {                       // the two pairs
+                const int j0 = J0 + 2 * pr;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (f16)act_apply(ac, saccv * acc[i][j0 + jj][4 * g + e]);
+                        const int c8 = 8 * jj + 2 * g + lh;
+                        *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = 8 * p + (lane >> 3), blk = lane & 7;
+                    const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                    f16x8 o = v;
+                    if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                    const int mr = mw + 32 * i + row, n = nw + 32 * j0 + 8 * blk;
+                    if (mr < a.M && n + 8 <= a.N) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
+                }
+            }
+            {                                                      // the single tile: 32 columns per row
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (f16)act_apply(ac, saccv * acc[i][JS][4 * g + e]);
+                    const int c8 = 2 * g + lh;
+                    *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int row = 16 * p + (lane >> 2), blk = lane & 3;
+                    const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                    f16x8 o = v;
+                    if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                    const int mr = mw + 32 * i + row, n = nw + 32 * JS + 8 * blk;
+                    if (mr < a.M && n + 8 <= a.N) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
+                }
+            }
+        }
+        wait_lds();
+    };
+    // ---- residuals and / or a per-row vector: 32 x 32 fp32 transposes (the sum is rounded once); a lane owns 8 consecutive
+    //      columns of one row.  The loads of step s + D are issued before step s is processed (ring of D steps in registers) ----
+    auto epilogue_rows = [&](auto un, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
+        constexpr bool RVROW = RV && decltype(un)::v == 0;         // the row vector was NOT folded into the accumulators
+        constexpr int STEPS = MI3 * NJ3;                           // (i, j): one accumulator tile per step
+        const int lane_e = lane_now();
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
+        f16* out = (f16*)a.out;
+        const f16* r1 = (const f16*)a.r1;
+        const f16* r2 = (const f16*)a.r2;
+        float s1v = a.s1, s2v = a.s2, saccv = a.s_acc;
+        asm volatile("" : "+v"(s1v), "+v"(s2v), "+v"(saccv));
+        int rv_div = a.rv_div, rv_mod_in = a.rv_mod_in, rv_mod_out = a.rv_mod_out;
+        asm volatile("" : "+s"(rv_div), "+s"(rv_mod_in), "+s"(rv_mod_out));
+        const int piece = lane & 3, rrow = lane >> 2;
+        // ring of D steps of loads in registers (8 VGPRs per residual, 16 for a per-row vector): the epilogue of a shallow-K
+        // launch is bound by the latency of exactly these loads
+        constexpr int REGS = (R1 ? 8 : 0) + (R2 ? 8 : 0) + (RVROW ? 16 : 0);
+        constexpr int D = RVROW ? 1 : (REGS <= 8 ? 6 : 3);       // (the per-row vector path is rare: tiles that straddle a frame)
+        struct StepLoads { f16x8 t1[2], t2[2]; f32x4 rv0[2], rv1[2]; };
+        StepLoads L[D];
+        auto step_loads = [&](int st, StepLoads& l) __attribute__((always_inline)) {
+            const int i = st / NJ3, j = st % NJ3;
+            const int n = nw + 32 * j + 8 * piece;
+            const int nc = n + 8 <= a.N ? n : 0;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                int m = mw + 32 * i + 16 * p + rrow;
+                m = m < a.M ? m : a.M - 1;
+                if (R1) l.t1[p] = *(const f16x8*)(r1 + (size_t)m * a.ldr1 + nc);
+                if (R2) l.t2[p] = *(const f16x8*)(r2 + (size_t)m * a.ldr2 + nc);
+                if (RVROW) {
+                    const int idx = ((m / rv_div) * a.rv_mul + (m % rv_mod_in)) % rv_mod_out;
+                    const float* q = a.rowvec + (size_t)idx * a.N + nc;
+                    l.rv0[p] = *(const f32x4*)q;
+                    l.rv1[p] = *(const f32x4*)(q + 4);
+                }
+            }
+        };
+#pragma unroll
+        for (int st = 0; st < D; ++st) step_loads(st, L[st]);
+        char* wr = eb + srow(l31);
+        const int wsw = ((l31 >> 1) & 3) | ((l31 & 1) << 2);
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const int i = st / NJ3, j = st % NJ3;
+            StepLoads& l = L[st % D];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                *(f32x4*)(wr + (((2 * g + lh) ^ wsw) << 4)) = v;
+            }
+            const int n = nw + 32 * j + 8 * piece;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int row = 16 * p + rrow;
+                const int rsw = ((row >> 1) & 3) | ((row & 1) << 2);
+                const f32x4 v0 = *(const f32x4*)(eb + srow(row) + (((2 * piece) ^ rsw) << 4));
+                const f32x4 v1 = *(const f32x4*)(eb + srow(row) + (((2 * piece + 1) ^ rsw) << 4));
+                f16x8 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x0 = v0[e], x1 = v1[e];
+                    if (RVROW) { x0 += l.rv0[p][e]; x1 += l.rv1[p][e]; }
+                    x0 *= saccv; x1 *= saccv;
+                    if (R1) { x0 += s1v * (float)l.t1[p][e]; x1 += s1v * (float)l.t1[p][4 + e]; }
+                    if (R2) { x0 += s2v * (float)l.t2[p][e]; x1 += s2v * (float)l.t2[p][4 + e]; }
+                    o[e] = (f16)x0; o[4 + e] = (f16)x1;
+                }
+                const int m = mw + 32 * i + row;
+                if (m < a.M && n + 8 <= a.N) *(f16x8*)(out + (size_t)m * a.ldo + n) = o;
+            }
+            if (st + D < STEPS) step_loads(st + D, L[st % D]);     // refill the ring slot just consumed
+        }
+        wait_lds();
+    };
+
+    int gt = 0;                                                    // K tiles consumed so far (ring slot = gt & 1)
+    for (int cl = walk.local; cl < walk.count; cl += walk.stride) {
+        const int tile = walk.start + cl;
+        const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
+        const int mw = tm * TBM3 + wm * MI3 * 32;                  // first output row / column of this wave
+        const int nw = tn * TBN3 + wn * NJ3 * 32;
+        int idx_u = -1;                                            // >= 0: the one row-vector row of this wave's 64 rows
+        if constexpr (RV) {
+            if (a.rv_mod_in == 1) {                                // idx(m) = ((m / div) * mul) % mod_out: a step function
+                int rv_div = a.rv_div;
+                asm volatile("" : "+s"(rv_div));
+                const int m0 = mw < a.M ? mw : a.M - 1, m1 = mw + 32 * MI3 - 1 < a.M ? mw + 32 * MI3 - 1 : a.M - 1;
+                const int q0 = m0 / rv_div, q1 = m1 / rv_div;
+                if (q0 == q1) idx_u = (q0 * a.rv_mul) % a.rv_mod_out;
+            }
+            idx_u = __builtin_amdgcn_readfirstlane(idx_u);
+        }
+        // accumulators start at bias (+ the wave's row of the row vector): loaded straight into them
+        {
+            const int lane_e = lane_now();
+            const int lh_e = lane_e >> 5;
+#pragma unroll
+            for (int j = 0; j < NJ3; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int n = nw + 32 * j + 8 * g + 4 * lh_e;
+                    n = n + 4 <= a.N ? n : 0;                       // columns beyond N are never stored
+                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                    if (a.bias) b = *(const f32x4*)(a.bias + n);
+                    if (RV && idx_u >= 0) b += *(const f32x4*)(a.rowvec + (size_t)idx_u * a.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[0][j][4 * g + e] = b[e]; acc[1][j][4 * g + e] = b[e]; }
+                }
+        }
+        if (grp == 1) __builtin_amdgcn_s_barrier();                // second wave group runs one barrier behind
+        for (int kt = 0; kt < nk; ++kt, ++gt) {
+            const int bo = (gt & 1) * SLOT, bn = SLOT - bo;        // ring slot of this K tile / of the next one
+            phase(IC<0>{}, bo, bn);
+            phase(IC<1>{}, bo, bn);
+            const int d = (gt & 1) ? -SLOT : SLOT;                 // the next K tile's ring slot
+            xa += d;
+            wa += d;
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();                // both groups meet again: equal barrier counts per tile
+
+        // ---- epilogue (no barriers; scratch = this wave's blocks of the free ring plane) --------------------------------
+        char* eb = smem + ((gt - 1) & 1) * SLOT + PLANE + wave * 1024;
+        if constexpr (R1 || R2) {
+            if (RV && idx_u >= 0) epilogue_rows(IC<1>{}, acc, mw, nw, eb);
+            else epilogue_rows(IC<0>{}, acc, mw, nw, eb);
+        } else if (RV && idx_u < 0) {
+            epilogue_rows(IC<0>{}, acc, mw, nw, eb);
+        } else if (wn == 0) {
+            if (RV || a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, eb);
+            else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<0>{}, acc, mw, nw, eb);
+            else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<0>{}, acc, mw, nw, eb);
+            else epilogue_light(IC<MOFA_ACT_GELU>{}, IC<0>{}, acc, mw, nw, eb);
+        } else {
+            if (RV || a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<1>{}, acc, mw, nw, eb);
+            else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<1>{}, acc, mw, nw, eb);
+            else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<1>{}, acc, mw, nw, eb);
+            else epilogue_light(IC<MOFA_ACT_GELU>{}, IC<1>{}, acc, mw, nw, eb);
+        }
+    }
+    // a wave must not retire with an LDS DMA in flight (the cursors' run-ahead past the last tile)
+    wait_vmcnt_only<0>();
+}
+
+typedef void (*igemm320_kern_t)(const mofa_igemm_args, const int, const int, const Aux);
+
+}  // namespace
+
+// (kind 7 = row vector + two residuals does not fit the register file beside 160 accumulators and occurs nowhere in the
+// model graph: it runs on the 256x256 tile)
+static const igemm320_kern_t k_igemm320[7] = {igemm320_f16_kernel<0>, igemm320_f16_kernel<1>, igemm320_f16_kernel<2>,
+                                               igemm320_f16_kernel<3>, igemm320_f16_kernel<4>, igemm320_f16_kernel<5>,
+                                               igemm320_f16_kernel<6>};
+
+int igemm320_init() {
+    for (igemm320_kern_t k : k_igemm320)
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES) != hipSuccess)
+            return MOFA_ELAUNCH;
+    return MOFA_OK;
+}
+
+// returns 0 launched, < 0 error, 1 not eligible (the caller falls back to another tile)
+int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stream) {
+    const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
+    if (kind >= 7 || !igemm_pipe_eligible(a, kind, (long long)taps * a->Cin)) return 1;
+    if ((long long)(a->N + TBN3) * taps * a->Cin * 2 >= 0x7ff00000LL) return 1;   // unclamped W row offsets stay below W_DEAD
+    const int tilesM = cdiv(a->M, TBM3), tilesN = cdiv(a->N, TBN3);
+    const long long nt = (long long)tilesM * tilesN;
+    if (nt > 0x7fffffffLL) return MOFA_EINVAL;
+    const Aux aux = igemm_pipe_aux(a, taps, tilesN);
+    int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
+    if (grid < 8) grid = 8;
+    hipLaunchKernelGGL(k_igemm320[kind], dim3(grid), dim3(512), LDS3_BYTES, stream, *a, tilesN, (int)nt, aux);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}

@@ -101,3 +101,6 @@ __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)"
 typedef void (*igemm_kern_t)(const mofa_igemm_args, const int, const int);
 int igemm8_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stream);
 int igemm8_init();
+// igemm320.hip: the 256x320 tile (same return convention: 0 launched, < 0 error, 1 not eligible)
+int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stream);
+int igemm320_init();

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmofa_hip.so")
 MODE_PLAIN, MODE_CONV3X3, MODE_CONVT3 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU_PAIR, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4
 PAD_SAME, PAD_TRAILING = 0, 1
-TILE_AUTO, TILE_128X128, TILE_192X128, TILE_256X256 = 0, 2, 4, 5
+TILE_AUTO, TILE_128X128, TILE_192X128, TILE_256X256, TILE_256X320 = 0, 2, 4, 5, 6
 
 
 class IgemmArgs(C.Structure):

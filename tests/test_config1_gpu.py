@@ -71,13 +71,13 @@ def test_config1_latents_and_frames_vs_cpu_oracle(full_width):
     assert e3 < 3e-2, e3
 
 
-@pytest.mark.parametrize("tile", ["192x128", "256x256"])
+@pytest.mark.parametrize("tile", ["192x128", "256x256", "256x320"])
 def test_config1_same_result_on_every_forced_tile(full_width, tile):
     """the whole full-width loop with every implicit-GEMM launch forced onto one tile (ineligible launches -- unaligned rows,
     activation on a residual kind -- keep the default): same latents within the fp16 tolerance"""
     from mofa_video_amd import lib, ops
     pipe, inp, ref_lat, _ = full_width
-    forced = {"192x128": lib.TILE_192X128, "256x256": lib.TILE_256X256}[tile]
+    forced = {"192x128": lib.TILE_192X128, "256x256": lib.TILE_256X256, "256x320": lib.TILE_256X320}[tile]
     orig = ops.igemm
 
     def igemm_forced(*a, **kw):

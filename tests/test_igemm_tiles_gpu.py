@@ -1,4 +1,4 @@
-"""Every implicit-GEMM output tile (128x128, 192x128, 256x256 phase-pipelined) x every epilogue kind
+"""Every implicit-GEMM output tile (128x128, 192x128, 256x256 and 256x320 phase-pipelined) x every epilogue kind
 x every addressing mode, ELEMENT-WISE against an fp32 PyTorch reference computed on the GPU, forced through
 ``mofa_igemm_args.tile`` so that the kernels the bench runs are the kernels compared here (the launcher's cost model
 picks 128x128 for everything small).  Shapes are ragged in M and N, span several rounds of persistent workgroups
@@ -13,7 +13,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-TILES = {"128x128": 2, "192x128": 4, "256x256": 5}
+TILES = {"128x128": 2, "192x128": 4, "256x256": 5, "256x320": 6}
+PIPE = ("256x256", "256x320")          # the 8-wave phase-pipelined kernels (igemm8.hip, igemm320.hip)
 # "rvu": a row vector that is constant over blocks of 1000 rows (idx = ((m / 1000) * 3) % 5) -- the time-embedding / per-clip
 # pattern: waves whose 128 rows lie inside one block take the load-once path of the 256x256 kernel, waves that straddle a
 # block boundary the per-row path, both in the same launch; plain "rv" (idx = ((m / 7) * 3 + m % 4) % 5) changes every row
@@ -96,7 +97,8 @@ def test_plain_gemm_every_tile_every_kind(ops, tile, kind):
     M, N, K = 10317, 2056, 192
     x, w = _h(M, K, seed=1), _h(N, K, seed=2, scale=0.1)
     bias, kw, apply = _epilogue(kind, M, N)
-    if kind == "rvusilu" and tile == "256x256":         # row vector + activation: 4-wave tiles only, a forced 256x256 is refused
+    refused = (kind == "rvusilu" and tile in PIPE) or (kind in ("r1r2rv", "r1r2rvu") and tile == "256x320")
+    if refused:       # row vector + activation: 4-wave tiles only; row vector + two residuals: not on the 256x320 tile
         from mofa_video_amd.lib import MofaHipError
         with pytest.raises(MofaHipError):
             ops.igemm(x, w, bias, tile=TILES[tile], **kw)
@@ -105,7 +107,7 @@ def test_plain_gemm_every_tile_every_kind(ops, tile, kind):
     _close(out, apply(x.float() @ w.float().t()), what=f"plain {tile} {kind}")
 
 
-@pytest.mark.parametrize("tile", list(TILES))
+@pytest.mark.parametrize("tile", [t for t in TILES if t != "256x320"])      # (the GEGLU pair kind has no 256x320 form)
 def test_geglu_pair_every_tile(ops, tile):
     from mofa_video_amd.weights import interleave_geglu
     M, Cc = 33000, 128                                  # N = 8 C = 1024: 129 x 4 tiles of 256x256
@@ -190,8 +192,11 @@ def test_forced_phase_pipelined_tile_rejects_unaligned_rows(ops):
     from mofa_video_amd.lib import MofaHipError
     x, w = _h(300, 64, seed=1), _h(68, 64, seed=2)      # N = 68: N % 8 != 0 -> no 16-byte output rows
     ops.igemm(x, w)                                      # fine on the default path
-    with pytest.raises(MofaHipError):
-        ops.igemm(x, w, tile=TILES["256x256"])
+    for t in PIPE:
+        with pytest.raises(MofaHipError):
+            ops.igemm(x, w, tile=TILES[t])
+    with pytest.raises(MofaHipError):                    # the GEGLU pair kind is refused by a forced 256x320
+        ops.igemm(_h(300, 64, seed=1), _h(128, 64, seed=2), act=2, tile=TILES["256x320"])
 
 
 # ---- the bench's own problem shapes (BASELINE config 2), reference in row chunks on the GPU ------------------------------
@@ -227,7 +232,7 @@ def test_bench_shape_geglu_l2(ops, tile):
     _close(out, h[:, :4 * Cc] * F.gelu(h[:, 4 * Cc:]), what=f"bench GEGLU L2 {tile}")
 
 
-@pytest.mark.parametrize("tile", ["192x128", "256x256"])
+@pytest.mark.parametrize("tile", ["192x128", "256x256", "256x320"])
 def test_bench_shape_conv3x3_l3_k11520(ops, tile):
     from mofa_video_amd.weights import pack_conv3x3
     n, Cc, H, W = 50, 1280, 9, 16                        # 7200 x 1280 x 11520 (K = 180 K tiles)
@@ -240,7 +245,7 @@ def test_bench_shape_conv3x3_l3_k11520(ops, tile):
     _close(out, ref, what=f"bench conv3x3 L3 {tile}")
 
 
-@pytest.mark.parametrize("tile", ["192x128", "256x256"])
+@pytest.mark.parametrize("tile", ["192x128", "256x256", "256x320"])
 def test_bench_shape_ff_out_l0_two_residuals(ops, tile):
     """460800 x 320 x 1280 with the AlphaBlender epilogue (s_acc, r1, r2) of the temporal feed-forward"""
     M, N, K = 460800, 320, 1280
@@ -252,6 +257,24 @@ def test_bench_shape_ff_out_l0_two_residuals(ops, tile):
         s = slice(i, i + 65536)
         ref = 0.4 * (x[s].float() @ w.float().t() + bias) + 0.4 * r1[s].float() + 0.6 * r2[s].float()
         _close(out[s], ref, what=f"bench ff-out L0 {tile} rows {i}")
+
+
+@pytest.mark.parametrize("tile", ["256x256", "256x320"])
+def test_bench_shape_conv3x3_l0_time_embedding(ops, tile):
+    """460800 x 320 x 2880: ResnetBlock2D conv1 of level 0 with the per-frame time-embedding row vector (uniform over every
+    wave's rows: 9216 rows per frame) -- the shape that reads X once on the 256x320 tile"""
+    from mofa_video_amd.weights import pack_conv3x3
+    n, Cc, H, W = 50, 320, 72, 128
+    x = torch.randn(n, Cc, H, W, generator=torch.Generator(device=DEV).manual_seed(50), device=DEV).half()
+    w = (torch.randn(Cc, Cc, 3, 3, generator=torch.Generator().manual_seed(51)) * 0.02).half().to(DEV)
+    xt = x.permute(0, 2, 3, 1).reshape(n * H * W, Cc).contiguous()
+    bias, rowvec = _f(Cc, seed=52), _f(2, Cc, seed=53)
+    out = ops.igemm(xt, pack_conv3x3(w.cpu()).to(DEV), bias, geom=ops.conv3x3_geom(H, W), rowvec=rowvec,
+                    rv=(25 * H * W, 1, 1, 1 << 30), tile=TILES[tile])
+    for f0 in range(0, n, 5):                            # (5 divides 25: a chunk never straddles the two clips)
+        ref = F.conv2d(x[f0:f0 + 5].float(), w.float(), None, padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
+        ref = ref + bias + rowvec[f0 // 25]
+        _close(out[f0 * H * W:(f0 + 5) * H * W], ref, what=f"bench conv3x3 L0 + temb {tile} frames {f0}")
 
 
 @pytest.mark.parametrize("tile", list(TILES))

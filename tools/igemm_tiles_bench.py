@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mofa_video_amd import lib, ops  # noqa: E402
 
 DEV = "cuda"
-TILES = [("128", lib.TILE_128X128), ("192", lib.TILE_192X128), ("256p", lib.TILE_256X256),
+TILES = [("128", lib.TILE_128X128), ("192", lib.TILE_192X128), ("256p", lib.TILE_256X256), ("320p", lib.TILE_256X320),
          ("auto", lib.TILE_AUTO)]
 
 # (mode, M-or-(n,H,W), N, Cin, epilogue, launches per denoise step [UNet + ControlNet], tag)
@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=4)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--quick", action="store_true", help="first 10 shapes only")
-    ap.add_argument("--tiles", default="128,192,256p,auto")
+    ap.add_argument("--tiles", default="192,256p,320p,auto")
     args = ap.parse_args()
     lib.load()
     tiles = [t for t in TILES if t[0] in args.tiles.split(",")]
@@ -101,11 +101,19 @@ def main():
     for (mode, Mg, N, Cin, epi, weight, tag) in shapes:
         call, fl = make_call(mode, Mg, N, Cin, epi)
         times = {n: [] for n, _ in tiles}
-        for n, t in tiles:                                   # warm-up
-            call(t)
+        ok = {}
+        for n, t in tiles:                                   # warm-up; a forced tile may refuse the launch (GEGLU on 256x320)
+            try:
+                call(t)
+                ok[n] = True
+            except lib.MofaHipError:
+                ok[n] = False
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for n, t in tiles:
+                if not ok[n]:
+                    times[n].append(float("inf"))
+                    continue
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
@@ -119,7 +127,7 @@ def main():
         K = Cin * (1 if mode == "gemm" else (9 if mode == "conv" else 3))
         print(f"{tag:30s} {M:8d} {N:6d} {K:6d} {epi:>6s} " + " ".join(f"{fl / med[n] / 1e12:7.0f}" for n, _ in tiles) + f"   {best}")
         for n in med:
-            tot[n] += weight * med[n]
+            tot[n] += weight * (med[n] if ok[n] else med["256p" if "256p" in med else best])
         tot_best += weight * med[best]
         tot_fl += weight * fl
         del call

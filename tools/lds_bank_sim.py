@@ -132,3 +132,39 @@ if __name__ == "__main__":
         w = sum(cycles("write_b128", f32_write(g, f)) for g in range(4))
         r = sum(cycles("read_b128", f32_read(p, h, f)) for p in range(2) for h in range(2))
         print(f"fp32 slab swizzle {name:28s}: writes {w} (ideal {4 * 8}), reads {r} (ideal {4 * 4})")
+
+
+# ---- igemm320 (csrc/igemm320.hip): K-half planes with 64-byte rows, chunk c of row r in slot c ^ ((r >> 2) & 3) ------------
+def frag_read_320(k2):
+    return [(lane & 31) * 64 + (((k2 * 2 + (lane >> 5)) ^ (((lane & 31) >> 2) & 3)) * 16) for lane in range(64)]
+
+
+def h16b_off(r, c8):       # 32 rows x 32 fp16 columns (64-byte rows); 8-byte chunk c8 at c8 ^ ((r >> 1) & 7)
+    return r * 64 + ((c8 ^ ((r >> 1) & 7)) * 8)
+
+
+def f32h_off(r, c):        # 16 rows x 32 fp32 columns (128-byte rows)
+    return r * 128 + ((c ^ (((r >> 1) & 3) | ((r & 1) << 2))) * 16)
+
+
+def igemm320_report():
+    for k2 in range(2):
+        report(f"igemm320 K loop fragment read, k2 = {k2}", "read_b128", frag_read_320(k2))
+    for g in range(4):
+        report(f"igemm320 fp16 32x32 write g = {g}", "write_b64", [h16b_off(lane & 31, 2 * g + (lane >> 5)) for lane in range(64)])
+    for p in range(2):
+        a = []
+        for lane in range(64):
+            row, piece = 16 * p + (lane >> 2), lane & 3
+            a.append(row * 64 + ((piece ^ ((row >> 2) & 3)) * 16))
+        report(f"igemm320 fp16 32x32 row read, pass {p}", "read_b128", a)
+    for h in range(2):
+        for g in range(4):
+            a = [f32h_off(lane & 15, 2 * g + (lane >> 5)) if ((lane & 31) >> 4) == h else None for lane in range(64)]
+            report(f"igemm320 fp32 16x32 half-wave write h = {h} g = {g}", "write_b128", a)
+    for half in range(2):
+        report(f"igemm320 fp32 16x32 row read, chunk {half}", "read_b128", [f32h_off(lane >> 2, 2 * (lane & 3) + half) for lane in range(64)])
+
+
+if __name__ == "__main__":
+    igemm320_report()
