@@ -31,14 +31,22 @@
 
 namespace {
 
-constexpr int WN3 = 2, MI3 = 2, NJ3 = 5;                       // wave grid 4 x 2, accumulator tiles per wave
-constexpr int TBM3 = 256, TBN3 = 320;
+constexpr int WN3 = 2, MI3 = 2;                                // wave grid 4 x 2, accumulator row tiles per wave
+constexpr int TBM3 = 256;
 constexpr int RBH = 64;                                        // bytes of one K half of a row
 constexpr int XPL = TBM3 * RBH;                                // X part of a plane (16 KB)
-constexpr int PLANE = (TBM3 + TBN3) * RBH;                     // 36 KB
-constexpr int SLOT = 2 * PLANE;                                // one K tile: 72 KB
-constexpr int LDS3_BYTES = 2 * SLOT;                           // 147456 (the epilogue transposes through a free ring plane)
-constexpr int LOOKAHEAD3 = 9;                                  // DMA instructions of the last two phases may be in flight
+// NJ = accumulator column tiles per wave: 5 -> the 256x320 tile (shipped).  NJ = 4 (a 256x256 tile with the same K-half
+// schedule, incl. the GEGLU pair epilogue below) was built and measured in round 3 and is NOT instantiated: it is 5-10 %
+// SLOWER than igemm8.hip's X-row split on every shape (profiles/r03_igemm_tiles_bench_with_ksplit256.log: GEGLU L0 / L1 / L2
+// 750 / 920 / 1039 against 833 / 1017 / 1141 TF/s) -- the 256x320 tile's advantage is its shape (load segment of 14 reads
+// + 4.5 DMA pieces under 640 MFMA cycles; 256x256: 12 + 4 under 512), not the K-half split.
+template <int NJ> struct Geo {
+    static constexpr int TBN = WN3 * NJ * 32;
+    static constexpr int PLANE = (TBM3 + TBN) * RBH;           // 36 KB / 32 KB
+    static constexpr int SLOT = 2 * PLANE;                     // one K tile
+    static constexpr int LDS_BYTES = 2 * SLOT;                 // 147456 / 131072 (the epilogue transposes through a free ring plane)
+    static constexpr int LOOKAHEAD = 4 + NJ;                   // DMA instructions of the last two phases may be in flight
+};
 
 struct Cursor3 {                    // one K-half plane of the persistent K-tile stream
     int local;                      // walk position of the output tile it is in
@@ -50,10 +58,12 @@ struct Cursor3 {                    // one K-half plane of the persistent K-tile
                                     // descriptor's range = zeros, no clamp)
 };
 
-template <int EPI>
+template <int EPI, int NJ3>
 __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_args a, const int tilesN, const int ntiles,
                                                               const Aux aux) {
-    constexpr bool R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0, RV = (EPI & EPI_RV) != 0;
+    constexpr bool R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0, RV = (EPI & EPI_RV) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
+    constexpr int TBN3 = Geo<NJ3>::TBN, PLANE = Geo<NJ3>::PLANE, SLOT = Geo<NJ3>::SLOT, LOOKAHEAD3 = Geo<NJ3>::LOOKAHEAD;
+    static_assert(!GEGLU || NJ3 == 4, "the GEGLU pair kind needs an even number of column tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY shared object
     TileWalk walk;
     walk.init(ntiles);
@@ -141,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         bglds16(rsx, c.xo1, c.ikc * 128, pl + (wave + 8) * 1024);
         bglds16(rsw, c.wo0, c.ksw * 128, pl + XPL + wave * 1024);
         bglds16(rsw, c.wo0 + wd1, c.ksw * 128, pl + XPL + (wave + 8) * 1024);
-        if (grp == p) bglds16(rsw, c.wo0 + wd2, c.ksw * 128, pl + XPL + (16 + (wave & 3)) * 1024);
+        if (NJ3 == 5 && grp == p) bglds16(rsw, c.wo0 + wd2, c.ksw * 128, pl + XPL + (16 + (wave & 3)) * 1024);
     };
     auto advance = [&](Cursor3& c, const int p) __attribute__((always_inline)) {
         ++c.ksw;
@@ -230,8 +240,8 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
     //      or 320 (wn = 1) of a 640-byte-aligned row: the pairs are (0,1) (2,3) + tile 4, or tile 0 + (1,2) (3,4), so that
     //      every pair starts on a 128-byte boundary -----------------------------------------------------------------------------
     auto epilogue_light = [&](auto ac, auto wnc, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
-        constexpr int J0 = decltype(wnc)::v ? 1 : 0;              // first tile of the first pair; the single tile is 4 - 4 * J0... (0 or 4)
-        constexpr int JS = decltype(wnc)::v ? 0 : 4;
+        constexpr int J0 = (NJ3 == 5 && decltype(wnc)::v) ? 1 : 0;   // first tile of the first pair
+        constexpr int JS = decltype(wnc)::v ? 0 : 4;                 // NJ = 5: the tile without a partner
         const int lane_e = lane_now();                             // (lane-derived offsets are not kept live across the K loop)
         const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
         f16* out = (f16*)a.out;
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
                     if (mr < a.M && n + 8 <= a.N) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
                 }
             }
-            {                                                      // the single tile: 32 columns per row
+            if constexpr (NJ3 == 5) {                              // the single tile: 32 columns per row
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f16x4 o;
@@ -282,6 +292,47 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
                     const int mr = mw + 32 * i + row, n = nw + 32 * JS + 8 * blk;
                     if (mr < a.M && n + 8 <= a.N) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
                 }
+            }
+        }
+        wait_lds();
+    };
+    // ---- GEGLU pair kind (NJ = 4): value tiles j = 0, 2 and gate tiles j = 1, 3 (weight rows interleaved in blocks of 32 at
+    //      load time) give 64 output columns per row and wave: one 32 x 64 fp16 transpose and four whole-line stores per
+    //      accumulator row block.  out = s_acc * val * gelu(s_acc * gate), erf GELU as x * Phi(x) (common.h) -------------------
+    auto epilogue_geglu = [&](auto s1c, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
+        constexpr bool SACC1 = decltype(s1c)::v != 0;              // s_acc == 1: the multiplies drop out
+        const int lane_e = lane_now();
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
+        f16* out = (f16*)a.out;
+        float saccv = a.s_acc;
+        asm volatile("" : "+v"(saccv));
+        const int nout = a.N / 2;
+        char* wr = eb + srow(l31);
+        const int wsw = (l31 >> 1) & 7, wpar = l31 & 1;
+#pragma unroll
+        for (int i = 0; i < MI3; ++i) {
+#pragma unroll
+            for (int jj = 0; jj < NJ3 / 2; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float val = acc[i][2 * jj][4 * g + e], gate = acc[i][2 * jj + 1][4 * g + e];
+                        if constexpr (SACC1) o[e] = (f16)(val * (gate * gelu_phi_f(gate)));
+                        else o[e] = (f16)(saccv * val * gelu_erf_f(saccv * gate));
+                    }
+                    const int c8 = 8 * jj + 2 * g + lh;
+                    *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+                }
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = 8 * p + (lane >> 3), blk = lane & 7;
+                const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                f16x8 o = v;
+                if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                const int mr = mw + 32 * i + row, n = nw / 2 + 8 * blk;
+                if (mr < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
             }
         }
         wait_lds();
@@ -412,12 +463,15 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
 
         // ---- epilogue (no barriers; scratch = this wave's blocks of the free ring plane) --------------------------------
         char* eb = smem + ((gt - 1) & 1) * SLOT + PLANE + wave * 1024;
-        if constexpr (R1 || R2) {
+        if constexpr (GEGLU) {
+            if (a.s_acc == 1.0f) epilogue_geglu(IC<1>{}, acc, mw, nw, eb);
+            else epilogue_geglu(IC<0>{}, acc, mw, nw, eb);
+        } else if constexpr (R1 || R2) {
             if (RV && idx_u >= 0) epilogue_rows(IC<1>{}, acc, mw, nw, eb);
             else epilogue_rows(IC<0>{}, acc, mw, nw, eb);
         } else if (RV && idx_u < 0) {
             epilogue_rows(IC<0>{}, acc, mw, nw, eb);
-        } else if (wn == 0) {
+        } else if (NJ3 == 4 || wn == 0) {
             if (RV || a.act == MOFA_ACT_NONE) epilogue_light(IC<MOFA_ACT_NONE>{}, IC<0>{}, acc, mw, nw, eb);
             else if (a.act == MOFA_ACT_SILU) epilogue_light(IC<MOFA_ACT_SILU>{}, IC<0>{}, acc, mw, nw, eb);
             else if (a.act == MOFA_ACT_RELU) epilogue_light(IC<MOFA_ACT_RELU>{}, IC<0>{}, acc, mw, nw, eb);
@@ -438,14 +492,13 @@ typedef void (*igemm320_kern_t)(const mofa_igemm_args, const int, const int, con
 }  // namespace
 
 // (kind 7 = row vector + two residuals does not fit the register file beside 160 accumulators and occurs nowhere in the
-// model graph: it runs on the 256x256 tile)
-static const igemm320_kern_t k_igemm320[7] = {igemm320_f16_kernel<0>, igemm320_f16_kernel<1>, igemm320_f16_kernel<2>,
-                                               igemm320_f16_kernel<3>, igemm320_f16_kernel<4>, igemm320_f16_kernel<5>,
-                                               igemm320_f16_kernel<6>};
-
+// model graph: it runs on the 4-wave tiles)
+static const igemm320_kern_t k_igemm320[7] = {igemm320_f16_kernel<0, 5>, igemm320_f16_kernel<1, 5>, igemm320_f16_kernel<2, 5>,
+                                               igemm320_f16_kernel<3, 5>, igemm320_f16_kernel<4, 5>, igemm320_f16_kernel<5, 5>,
+                                               igemm320_f16_kernel<6, 5>};
 int igemm320_init() {
     for (igemm320_kern_t k : k_igemm320)
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS3_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
     return MOFA_OK;
 }
@@ -454,14 +507,15 @@ int igemm320_init() {
 int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stream) {
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
     if (kind >= 7 || !igemm_pipe_eligible(a, kind, (long long)taps * a->Cin)) return 1;
-    if ((long long)(a->N + TBN3) * taps * a->Cin * 2 >= 0x7ff00000LL) return 1;   // unclamped W row offsets stay below W_DEAD
-    const int tilesM = cdiv(a->M, TBM3), tilesN = cdiv(a->N, TBN3);
+    constexpr int tbn = Geo<5>::TBN;
+    if ((long long)(a->N + tbn) * taps * a->Cin * 2 >= 0x7ff00000LL) return 1;   // unclamped W row offsets stay below W_DEAD
+    const int tilesM = cdiv(a->M, TBM3), tilesN = cdiv(a->N, tbn);
     const long long nt = (long long)tilesM * tilesN;
     if (nt > 0x7fffffffLL) return MOFA_EINVAL;
     const Aux aux = igemm_pipe_aux(a, taps, tilesN);
     int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
     if (grid < 8) grid = 8;
-    hipLaunchKernelGGL(k_igemm320[kind], dim3(grid), dim3(512), LDS3_BYTES, stream, *a, tilesN, (int)nt, aux);
+    hipLaunchKernelGGL(k_igemm320[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a, tilesN, (int)nt, aux);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
