@@ -309,8 +309,7 @@ def main():
     cfg = args.config
     pipe = build_config_pipeline(dev, cfg, seed=0)
     mode = args.mode if world > 1 else "single"
-    if mode == "shard" and cfg == 3:
-        mode = "replicas"                                   # one 25-frame window: nothing to shard in the window loop
+    comm_paths = None
     if mode == "shard":
         # every rank must see the same clip; partition = mofa_video_amd/parallel.py.  A failure here is an error: a
         # strong-scaling request must never silently turn into independent replicas
@@ -327,6 +326,7 @@ def main():
             probe = torch.ones(4, device=dev, dtype=torch.float64)          # exercise the collectives once
             comm.all_reduce_sum(probe, pipe.parallel.lay.frame_group)
             comm.all_gather(probe, pipe.parallel.lay.pair_group)
+            comm_paths = pipe.parallel.self_check(dev)                      # fast paths verified on THIS transport, or switched off
         torch.cuda.synchronize()
     inp = config_inputs(dev, cfg, seed=42 + (rank if mode == "replicas" else 0))
 
@@ -423,7 +423,7 @@ def main():
                        "num_frames": nfr, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
                        "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
-                       "output_finite": finite,
+                       "output_finite": finite, "comm_paths": comm_paths,
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},
             "roofline": roofline,
         }

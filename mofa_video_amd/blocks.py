@@ -337,7 +337,7 @@ class TransformerSpatioTemporal:
             # projection runs, and the attention kernel masks the padding frames of the shorter shards.
             Cc, par = self.C, c.par
             fn = self.tnorm1(f)
-            if par.kv_slots <= 32:
+            if par.kv_slots <= 32 and par.kv_inplace:
                 kv, own = par.kv_buffer(HW, 2 * Cc, fn.device)
                 self.tattn1.kv_into(fn, own)
                 work = par.kv_gather_begin(kv, HW)
@@ -345,7 +345,8 @@ class TransformerSpatioTemporal:
                 work.wait()
                 a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.kv_slots, HW, self.heads,
                                       head_dim=self.tattn1.head_dim, Tq=T, key_mask=par.kv_mask)
-            else:   # more than 32 key slots after padding (e.g. 31 frames over 3 shards): compact to T_full frames
+            else:   # more than 32 key slots after padding (e.g. 31 frames over 3 shards), or the in-place path failed
+                    # its self-check on this transport (parallel.FrameParallel.self_check): compact to T_full frames
                 q, k, v = self.tattn1.qkv(fn)
                 kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
                 ops.copy2d(k, kv[:, :Cc])

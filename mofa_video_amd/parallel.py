@@ -212,6 +212,62 @@ class FrameParallel:
         self.lay, self.comm = layout, comm
         self.T_full, self.T_loc, self.f0, self.f1 = layout.T, layout.T_loc, layout.f0, layout.f1
         self.p2p = p2p and isinstance(comm, TorchComm)
+        self.kv_inplace = True      # temporal attention K|V: in-place asynchronous all_gather_into_tensor (else: compacting gather)
+
+    def self_check(self, device):
+        """Runs the two transport-specific fast paths once on small known data -- the in-place asynchronous
+        all_gather_into_tensor whose input aliases its output slot (K|V exchange) and the batched isend / irecv halo
+        exchange -- and compares with what the plain list all_gather delivers.  A path that raises or returns wrong data is
+        switched off ON EVERY RANK of the frame group (the verdict is all-reduced), so the run continues on the conservative
+        path (pad + all_gather + compaction, as for more than 32 key slots; all_gather-based halo).  Returns a dict for the
+        caller to report.  Meant for the first run on a new transport: bench.py calls it in shard mode."""
+        lay, grp = self.lay, self.lay.frame_group
+        report = {"kv_gather": "in-place all_gather_into_tensor", "halo": "batched p2p" if self.p2p else "all_gather"}
+        if len(grp) == 1:
+            return report
+        rows, C = 8, 16
+        mine = torch.full((lay.T_loc * rows, C), float(lay.shard + 1), dtype=torch.float16, device=device)
+        ref = self.comm.all_gather(torch.full((lay.T_max * rows, C), float(lay.shard + 1), dtype=torch.float16, device=device), grp)
+        # --- K|V path
+        ok = 1.0
+        try:
+            buf, own = self.kv_buffer(rows, C, device)
+            buf.zero_()
+            own.copy_(mine)
+            self.kv_gather_begin(buf, rows).wait()
+            slot = lay.T_max * rows
+            for s_, (a, b) in enumerate(lay.bounds):
+                n = (b - a) * rows
+                if not torch.equal(buf[s_ * slot:s_ * slot + n], ref[s_][:n]):
+                    ok = 0.0
+        except Exception as e:  # noqa: BLE001
+            ok = 0.0
+            report["kv_gather_error"] = repr(e)[:200]
+        flag = torch.tensor([ok], dtype=torch.float64, device=device)
+        self.comm.all_reduce_sum(flag, grp)
+        if float(flag.item()) < len(grp):
+            self.kv_inplace = False
+            report["kv_gather"] = "compacting all_gather (the in-place path failed its self-check)"
+        # --- halo path
+        if self.p2p:
+            ok = 1.0
+            try:
+                first = torch.full((rows, C), 10.0 + lay.shard, dtype=torch.float16, device=device)
+                last = torch.full((rows, C), 20.0 + lay.shard, dtype=torch.float16, device=device)
+                fp, fn = self.comm.exchange_halo(first, last, lay.prev_rank, lay.next_rank)
+                if lay.prev_rank is not None and not bool((fp == 20.0 + lay.shard - 1).all()):
+                    ok = 0.0
+                if lay.next_rank is not None and not bool((fn == 10.0 + lay.shard + 1).all()):
+                    ok = 0.0
+            except Exception as e:  # noqa: BLE001
+                ok = 0.0
+                report["halo_error"] = repr(e)[:200]
+            flag = torch.tensor([ok], dtype=torch.float64, device=device)
+            self.comm.all_reduce_sum(flag, grp)
+            if float(flag.item()) < len(grp):
+                self.p2p = False
+                report["halo"] = "all_gather (the batched p2p path failed its self-check)"
+        return report
 
     # temporal GroupNorm -----------------------------------------------------------------------------------
     def reduce_gn(self, sums):

@@ -395,6 +395,47 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         self.drag_controlnet = drag_controlnet
         self.overlap_decode = overlap_decode
 
+    def _single_window_sharded(self, lat, il, emb, cond, flow, dflow, landmarks, mask, timesteps, h, w, height, width, gmin, gmax,
+                               cn_scale, traj_scale, callback):
+        """the window loop for ONE window == the clip, on this rank's CFG half / frame shard (see __call__)"""
+        unet, cn, drag, sch, dev = self.unet, self.controlnet, self.drag_controlnet, self.scheduler, self.device
+        T = lat.shape[0]
+        sh = _Shard(self.parallel, T)
+        f0, f1, Tl, Bl, half, fpar = sh.f0, sh.f1, sh.Tl, sh.Bl, sh.half, sh.fpar
+        hybrid = dflow is not None
+        # window = frame 0 + frames 1 .. T-1 with the flows of frames 1 .. T-1 (svdxt_pipeline_ctrlnet_loop.py:470-476)
+        cf = cn.prepare_condition(cond[:1], flow[:1, 0:T - 1], landmarks[:, 0:T], frames=(f0, f1))
+        cd = drag.prepare_condition(cond[:1], dflow[:1, 0:T - 1], frames=(f0, f1)) if hybrid else None
+        masks = _resized_masks(mask, height, width, h, w, dev) if hybrid else None
+        lat = lat[f0:f1].contiguous()
+        gspan = (gmax - gmin) / max(T - 1, 1)
+        g0, g1 = gmin + gspan * f0, gmin + gspan * (f1 - 1)
+        added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
+        c_f, c_d, c_u = Ctx(Bl, Tl), Ctx(Bl, Tl), Ctx(Bl, Tl)
+        rows = Tl * h * w
+        x_in = torch.zeros((2 * rows, unet.in_ld), dtype=torch.float16, device=dev)
+        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
+        self._num_timesteps = len(timesteps)
+        for i, t in enumerate(timesteps):
+            sigma, sigma_next = sch.sigma_pair(i)
+            ops.prepare_model_input(lat, il, x_in, sigma)
+            cn.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_f, half=half, par=fpar)
+            down, mid = cn.forward_tokens(x_loc, c_f, h, w, cf, cn_scale)
+            if hybrid:
+                drag.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_d, half=half, par=fpar)
+                dd, md = drag.forward_tokens(x_loc, c_d, h, w, cd, traj_scale)
+                down, mid = _blend_residuals(down, mid, dd, md, masks, Bl * Tl)
+            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_u, half=half, par=fpar)
+            noise = unet.forward_tokens(x_loc, c_u, h, w, down, mid)
+            if Bl == 1:
+                noise = sh.par.gather_cfg(noise)
+            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
+            lat = self._round(lat)
+            lat = self._callback(callback, i, t, lat, (1, Tl, 4, h, w))
+        if fpar is not None:
+            lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
+        return lat
+
     @torch.no_grad()
     def __call__(self, image=None, controlnet_condition=None, controlnet_flow=None, landmarks=None, window_size: int = 25,
                  stride: int = 12, height: int = 576, width: int = 1024, num_frames: Optional[int] = None,
@@ -427,6 +468,23 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         flow = controlnet_flow.to(dev, torch.float32)
         dflow = drag_flow.to(dev, torch.float32) if hybrid else None
         views = window_views(N, Tw, stride)
+        from .parallel import FrameParallel
+        if isinstance(self.parallel, FrameParallel):
+            # ONE window that is the whole clip (N == window_size: every view is frames 1 .. N-1 behind frame 0): the loop
+            # degenerates to the plain denoise loop -- value = k * stepped window, count = k -- so the clip is frame-sharded
+            # exactly like FlowControlNetPipeline / HybridFlowControlNetPipeline (2-way CFG x frame shards).  Several
+            # windows cannot be frame-sharded (they overlap in time): those take parallel.WindowParallel.
+            if len(set(views)) != 1 or N != Tw:
+                raise ValueError(f"frame sharding (parallel.FrameParallel) needs a single window (num_frames == window_size); "
+                                 f"{len(set(views))} distinct windows of {Tw} over {N} frames: use parallel.WindowParallel")
+            lat = self._single_window_sharded(lat, il, emb, cond, flow, dflow, landmarks, mask, timesteps, h, w, height, width,
+                                              min_guidance_scale, max_guidance_scale, controlnet_cond_scale, ctrl_scale_traj,
+                                              callback_on_step_end)
+            sh = _Shard(self.parallel, N)
+            frames = self._decode(lat.reshape(1, N, 4, h, w), N, decode_chunk_size, output_type, sh)
+            if not return_dict:
+                return frames, controlnet_flow
+            return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
         # adapter state per DISTINCT window is timestep-invariant: computed once per clip (the reference recomputes it
         # every step; its last view often repeats the previous one -- SURVEY 3.5 -- and is computed once here)
         conds, dconds = {}, {}
@@ -517,7 +575,8 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
                                 if ci not in stream_chunks and s1 <= newf:
                                     with torch.cuda.stream(side):
                                         side.wait_event(ready)
-                                        z = lat_r[s0:s1]
+                                        lat_r.record_stream(side)         # (lat_r may be a temporary of the main stream: keep
+                                        z = lat_r[s0:s1]                  #  its block out of the allocator until the decode ran)
                                         stream_chunks[ci] = self.vae.decode(z, num_frames=s1 - s0,
                                                                             _prescale=1.0 / self.vae.config.scaling_factor)
                             frontier = newf

@@ -38,4 +38,22 @@ def check_frame_exchanges(rank, world, T, HW, C, device):
     assert bin(par.kv_mask).count("1") == T
 
     assert torch.equal(par.gather_frames(mine, HW), full)                 # the compacting gather (final latents)
+
+    # transport self-check: both fast paths pass on a working transport; a path that delivers wrong data is switched off on
+    # EVERY rank of the group (here: rank 0's in-place gather is sabotaged) and the conservative path still works
+    rep = par.self_check(device)
+    assert par.kv_inplace and rep["kv_gather"].startswith("in-place"), rep
+    orig = par.kv_gather_begin
+    if rank == 0:
+        def broken(buf_, rows_):
+            w = orig(buf_, rows_)
+            w.wait()
+            buf_[lay.T_max * rows_, 0] = 777.0                             # corrupt the first element of shard 1's slot
+            return w
+        par.kv_gather_begin = broken
+    rep = par.self_check(device)
+    par.kv_gather_begin = orig
+    assert not par.kv_inplace and "compacting" in rep["kv_gather"], (rank, rep)
+    assert torch.equal(par.gather_frames(mine, HW), full)
+    par.kv_inplace = True
     return par, full, mine

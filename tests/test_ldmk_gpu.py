@@ -192,3 +192,57 @@ def test_keypoint_loop_window_parallel_equals_single_rank(models, world):
     assert not errors, errors
     for r, o in enumerate(results):
         assert torch.equal(o, ref), (r, rel_l2(o, ref))
+
+
+@pytest.mark.parametrize("world,hybrid", [(2, False), (4, False), (4, True)])
+def test_keypoint_single_window_frame_sharded_equals_single_rank(models, world, hybrid):
+    """BASELINE config 3 is ONE window that is the whole clip (num_frames == window_size): with a parallel.FrameParallel the
+    Keypoint pipeline frame-shards it (2-way CFG x frame shards) like the Traj / Hybrid pipelines -- it must reproduce the
+    single-rank window loop (whose two identical views average to the stepped window); several windows are refused."""
+    import threading
+
+    from mofa_video_amd.parallel import FrameParallel, Layout, ThreadComm, ThreadWorld
+    from mofa_video_amd.pipeline import KeypointFlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    of, od, ou, hf, hd, hu = models
+    T = 5
+    inp = synthetic_inputs(T, H, W, cross_dim=CROSS, seed=48)
+    lm = synthetic_landmarks(T, H, W, seed=49)
+    extra = {}
+    if hybrid:
+        mask = torch.zeros(1, 1, H, W)
+        mask[:, :, H // 4:3 * H // 4, W // 4:3 * W // 4] = 1.0
+        extra = dict(drag_flow=synthetic_inputs(T, H, W, cross_dim=CROSS, seed=50)["flow"] * 0.5, mask=mask, ctrl_scale_traj=0.8)
+
+    def run(parallel=None, frames=T, window=T):
+        pipe = KeypointFlowControlNetPipeline(unet=hu, controlnet=hf, drag_controlnet=hd if hybrid else None,
+                                              scheduler=EulerDiscreteScheduler(), parallel=parallel)
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=window,
+                    stride=max(window // 2, 1), height=H, width=W, num_frames=frames, num_inference_steps=2,
+                    latents=inp["latents"], output_type="latent", image_embeddings=inp["image_embeddings"],
+                    image_latents=inp["image_latents"], **extra).frames
+    ref = run()
+    tw = ThreadWorld(world)
+    results, errors = [None] * world, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            results[r] = run(FrameParallel(Layout(world, r, T), ThreadComm(tw, r)))
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            for b in tw.barriers.values():
+                b.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    for r, o in enumerate(results):
+        e = rel_l2(o, ref)
+        print(f"keypoint single window (hybrid={hybrid}) world {world} rank {r}: latents rel-L2 vs single rank {e:.3e}")
+        assert tuple(o.shape) == tuple(ref.shape) and e < 2e-3, (r, e)
+    # several windows cannot be frame-sharded
+    with pytest.raises(ValueError):
+        run(FrameParallel(Layout(1, 0, T), ThreadComm(ThreadWorld(1), 0)), frames=T, window=T - 1)
