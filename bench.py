@@ -243,15 +243,41 @@ def _cpu_baseline_worker():
           return_dict=False, added_time_ids=ids)
     dt = time.time() - t0
     tflop = fc.get_total_flops() / 1e12
-    print(json.dumps(dict(cores=cores, avail=avail, setup=setup, dt=dt, tflop=tflop)))
+    del u, c, dr, mr
+    # second part of the sample: the temporal VAE decoder at the FULL 576x1024 resolution on a 2-frame chunk (its
+    # work is linear in the frames of a chunk; a whole 8-frame chunk is 54 TFLOP, minutes of host time)
+    from oracle.vae import AutoencoderKLTemporalDecoder
+    t0 = time.time()
+    with torch.device("meta"):
+        v = AutoencoderKLTemporalDecoder()
+    v = v.to_empty(device="cpu")
+    with torch.no_grad():
+        for name, p in v.named_parameters():
+            if p.dim() > 1:
+                n = p.numel()
+                p.view(-1).copy_((torch.arange(n, dtype=torch.float32) % 251 - 125.0) * (p[0].numel() ** -0.5 / 125.0))
+            elif name.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.zero_()
+    setup += time.time() - t0
+    z = torch.randn(2, 4, H // 8, W // 8, generator=g)
+    fcv = FlopCounterMode(display=False)
+    t0 = time.time()
+    with torch.no_grad(), fcv:
+        v.decode(z, num_frames=2)
+    dtv = time.time() - t0
+    print(json.dumps(dict(cores=cores, avail=avail, setup=setup, dt=dt, tflop=tflop, dt_vae=dtv,
+                          tflop_vae=fcv.get_total_flops() / 1e12)))
 
 
 def cpu_baseline(timeout=420):
     """The CPU oracle (fp32 PyTorch restatement of the reference pipeline, oracle/) on a BOUNDED sample of the same
-    workload: ONE denoise step (MOFA-Adapter/ControlNet + UNet, CFG batch 2) of the full-size SVD-XT architecture at
-    8 frames x 256x256 (BASELINE config[0] geometry), FLOPs counted by torch's FlopCounterMode, converted to the metric's unit through the
-    analytic work model (225.5 TFLOP per denoised frame at 25 f 576x1024).  Runs in a child process
-    with a hard timeout so the default bench stays within minutes on any host."""
+    workload, two parts: ONE denoise step (MOFA-Adapter/ControlNet + UNet, CFG batch 2) of the full-size SVD-XT architecture
+    at 8 frames x 256x256 (BASELINE config[0] geometry), and the temporal VAE decoder on a 2-frame chunk at the full 576x1024;
+    FLOPs counted by torch's FlopCounterMode, each part converted to seconds per clip through the analytic work model
+    (218.58 TFLOP per denoise step, 173.57 TFLOP of decode at 25 f 576x1024) with ITS OWN measured rate.  Runs in
+    a child process with a hard timeout so the default bench stays within minutes on any host."""
     import subprocess
     try:
         r = subprocess.run([sys.executable, "-c", "import bench; bench._cpu_baseline_worker()"], cwd=ROOT,
@@ -260,12 +286,17 @@ def cpu_baseline(timeout=420):
     except Exception as e:  # noqa: BLE001
         return dict(value=None, unit="denoised frames/sec", cores=0, kind="port",
                     sample=f"CPU oracle sample did not finish within {timeout} s ({type(e).__name__})")
-    cpu_tflops = d["tflop"] / d["dt"]
-    return dict(value=cpu_tflops / 225.5, unit="denoised frames/sec", cores=d["cores"], kind="port",
-                sample=(f"oracle (fp32 torch CPU, {d['cores']} threads of {d['avail']} available): one denoise step of the "
-                        f"full-size SVD-XT UNet + MOFA ControlNet at 8 f x 256x256, CFG batch 2 = {d['tflop']:.3f} TFLOP "
-                        f"(FlopCounterMode) in {d['dt']:.1f} s = {cpu_tflops:.4f} TFLOP/s (model setup {d['setup']:.0f} s "
-                        f"untimed); value = that rate / 225.5 TFLOP per denoised frame at 25 f 576x1024"))
+    # whole-clip time on the host = 25 steps x (218.58 TFLOP per step at the UNet sample's rate) + 173.57 TFLOP of decode at the
+    # VAE sample's rate (SURVEY 8d work model for 25 f 576x1024, single adapter)
+    r_unet, r_vae = d["tflop"] / d["dt"], d["tflop_vae"] / d["dt_vae"]
+    clip_s = 25 * 218.58 / r_unet + 173.57 / r_vae
+    return dict(value=25.0 / clip_s, unit="denoised frames/sec", cores=d["cores"], kind="port",
+                sample=(f"oracle (fp32 torch CPU, {d['cores']} threads of {d['avail']} available), two parts: (1) one denoise step of "
+                        f"the full-size SVD-XT UNet + MOFA ControlNet at 8 f x 256x256, CFG batch 2 = {d['tflop']:.3f} TFLOP "
+                        f"(FlopCounterMode) in {d['dt']:.1f} s = {r_unet:.4f} TFLOP/s; (2) the temporal VAE decoder on a 2-frame chunk "
+                        f"at the full 576x1024 = {d['tflop_vae']:.3f} TFLOP in {d['dt_vae']:.1f} s = {r_vae:.4f} TFLOP/s (model set-up "
+                        f"{d['setup']:.0f} s untimed); value = 25 frames / (25 x 218.58 TFLOP / rate 1 + 173.57 TFLOP / rate 2) = "
+                        f"25 / {clip_s:.0f} s"))
 
 
 def main():

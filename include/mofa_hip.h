@@ -78,7 +78,12 @@ typedef struct mofa_igemm_args {
                          * leading padding, taps start at input pixel stride*o (diffusers Downsample2D(padding=0) of the
                          * VAE encoder: F.pad(x, (0,1,0,1)) then a stride-2 conv)                                    */
     int32_t tile;       /* MOFA_TILE_AUTO (0): the launcher's cost model picks the output tile; any other MOFA_TILE_*
-                         * forces it (parity tests run every shape through every tile).  sizeof(mofa_igemm_args) = 168 */
+                         * forces it (parity tests run every shape through every tile) */
+    void* workspace;    /* optional device scratch (16-byte aligned) owned by the caller, private to `stream` for the duration
+                         * of the launch, or NULL.  With it the 256x320 tile splits the tiles of a partial last round of
+                         * workgroups along K (fp32 partial tiles here, added in a fixed order by a fix-up launch on the same
+                         * stream); without it every tile is computed whole.  Same result up to fp32 summation order.          */
+    int64_t workspace_bytes;   /* 84 MB (256 partial tiles of 256 x 320 fp32) is never exceeded.  sizeof(mofa_igemm_args) = 184 */
 } mofa_igemm_args;
 enum { MOFA_PAD_SAME = 0, MOFA_PAD_TRAILING = 1 };
 /* output tiles of the implicit GEMM: 4 waves / 2 workgroups per CU (128x128, 192x128) and the 8-wave phase-pipelined

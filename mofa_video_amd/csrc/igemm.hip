@@ -545,7 +545,10 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
             // epilogues move 25 % more outputs per tile through a smaller scratch
             static const double epi320[8] = {3.0, 10.0, 10.0, 11.5, 3.5, 10.5, 10.5, 12.0};   // fitted: profiles/r03_igemm_tiles_bench.log
             const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 320);
-            const double cost = (double)((t + n_cu - 1) / n_cu) * 256 * 320 * 0.58 * (1.0 + epi320[kind] / nk);
+            // a partial last round split along K (igemm320_split) costs 1 / S of a round + the fix-up pass
+            const int S = igemm320_split(t, (int)nk, n_cu, a->workspace ? a->workspace_bytes : 0);
+            const double rounds = S > 1 ? (double)(t / n_cu) + 1.0 / S + 0.12 : (double)((t + n_cu - 1) / n_cu);
+            const double cost = rounds * 256 * 320 * 0.58 * (1.0 + epi320[kind] / nk);
             if (cost < best) { best = cost; choice = MOFA_TILE_256X320; }
         }
     }

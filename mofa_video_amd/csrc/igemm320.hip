@@ -53,12 +53,18 @@ struct Cursor3 {                    // one K-half plane of the persistent K-tile
     int ikc, ksw, ky, kx;           // K tile within the tap / overall, tap coordinates (convT3: ky = tap)
     int gx0, gx1;                   // packed row geometry of this wave's two X pieces (16 rows each)
     unsigned xo0, xo1;              // source row of the current tap + this lane's swizzled chunk, bytes from aux.xbase
+    int phase;                      // 0: whole tiles of the walk, 1: this workgroup's split-K item, 2: past the end
+    int kend;                       // first K tile beyond the current item's K range
     unsigned wo0;                   // weight row of W piece `wave` + this lane's swizzled chunk, bytes from a.w; the
                                     // wave's other pieces are a uniform number of rows further (rows beyond N: out of the
                                     // descriptor's range = zeros, no clamp)
 };
 
-template <int EPI, int NJ3>
+// SPLIT: after its whole tiles (tile ids [0, ntiles)) workgroup b < aux.nitems computes ONE split-K item: K slice b % nsplit of
+// remainder tile aux.tile0 + b / nsplit (see igemm320_launch).  Its accumulators start at zero and leave as an fp32 partial
+// tile in aux.ws; bias, row vector, residuals and activation are applied by igemm320_fixup_kernel.  The item follows the
+// whole tiles in the same persistent stream (the cursors prefetch it during the last whole tile's epilogue).
+template <int EPI, int NJ3, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_args a, const int tilesN, const int ntiles,
                                                               const Aux aux) {
     constexpr bool R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0, RV = (EPI & EPI_RV) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
@@ -67,7 +73,8 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY shared object
     TileWalk walk;
     walk.init(ntiles);
-    if (walk.local >= walk.count) return;
+    const bool has_item = SPLIT && (int)blockIdx.x < aux.nitems;
+    if (walk.local >= walk.count && !has_item) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;                                     // waves w and w + 4 share a SIMD
@@ -127,10 +134,31 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         const unsigned off = (unsigned)row * (unsigned)aux.ldxb + (unsigned)swzb;
         return ok ? off : XO_INVALID;
     };
+    // position in the workgroup's stream -> output tile and K-tile range [kb, ke)
+    auto item_decode = [&](int phase, int local, int& tile, int& kb, int& ke) __attribute__((always_inline)) {
+        tile = walk.start + (phase == 0 ? local : 0); kb = 0; ke = nk;
+        if constexpr (SPLIT) {
+            const int q = fdiv((int)blockIdx.x, aux.nsplit_d), ks = (int)blockIdx.x - q * aux.nsplit;
+            const int kb1 = fdiv(ks * nk, aux.nsplit_d), ke1 = fdiv((ks + 1) * nk, aux.nsplit_d);
+            const bool it = phase == 1;
+            tile = it ? aux.tile0 + q : tile;
+            kb = it ? kb1 : 0;
+            ke = it ? ke1 : nk;
+        }
+    };
+    auto next_pos = [&](int& phase, int& local) __attribute__((always_inline)) {
+        if (phase == 0) {
+            local += walk.stride;
+            if (local >= walk.count) phase = has_item ? 1 : 2;
+        } else {
+            phase = 2;
+        }
+    };
     auto cur_setup = [&](Cursor3& c, const int p) __attribute__((always_inline)) {
         // branch-free on purpose (selects on the uniform `live`; see igemm8.hip)
-        const bool live = c.local < walk.count;
-        const int tile = walk.start + (live ? c.local : 0);
+        const bool live = c.phase < 2;
+        int tile, kb, ke;
+        item_decode(c.phase, c.local, tile, kb, ke);
         const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
         const int l = lane_now(), r_l = l >> 2;
         const int g0 = pack_geo(tm * TBM3 + 16 * wave + r_l), g1 = pack_geo(tm * TBM3 + 16 * (wave + 8) + r_l);
@@ -139,6 +167,15 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         const unsigned wo = (unsigned)(tn * TBN3 + 16 * wave + r_l) * (unsigned)(Ktot * 2) + swz_bytes(l, p);
         c.wo0 = live ? wo : W_DEAD;
         c.ikc = 0; c.ksw = 0; c.ky = 0; c.kx = 0;
+        c.kend = ke;
+        if constexpr (SPLIT) {                                     // a slice may start in the middle of a tap
+            const int tap = fdiv(kb, aux.kpt_d);
+            c.ikc = kb - tap * kpt;
+            c.ksw = kb;
+            if (a.mode == MOFA_MODE_CONV3X3) { c.ky = fdiv(tap, aux.ks_d); c.kx = tap - c.ky * ks_; } else c.ky = tap;
+            c.xo0 = tap_src(c.gx0, c.ky, c.kx, swz_bytes(l, p));
+            c.xo1 = tap_src(c.gx1, c.ky, c.kx, swz_bytes(l, p));
+        }
     };
     auto issue = [&](Cursor3& c, const int p, const int slot) __attribute__((always_inline)) {
         if (c.ikc == 0) {
@@ -159,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
             c.ikc = 0;
             if (a.mode == MOFA_MODE_CONV3X3) { if (++c.kx == ks_) { c.kx = 0; ++c.ky; } } else ++c.ky;
         }
-        if (c.ksw == nk) { c.local += walk.stride; cur_setup(c, p); }
+        if (c.ksw == c.kend) { next_pos(c.phase, c.local); cur_setup(c, p); }
     };
 
     // ---- consumer side ----------------------------------------------------------------------------------------------
@@ -175,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
 
     Cursor3 ca, cb;                                                // plane 0 stream, plane 1 stream
     ca.local = cb.local = walk.local;
+    ca.phase = cb.phase = walk.local < walk.count ? 0 : 1;     // (no whole tile: the workgroup was kept for its split-K item)
     cur_setup(ca, 0);
     cur_setup(cb, 1);
     // prologue: K tile 0 complete, plane 0 of K tile 1
@@ -416,9 +454,42 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         wait_lds();
     };
 
+    // ---- split-K: the fp32 partial tile, row-major [256][TBN], through the same 32 x 32 fp32 transposes ------------------------
+    auto epilogue_dump = [&](f32x16 (&acc)[MI3][NJ3], float* wst, char* eb) __attribute__((always_inline)) {
+        const int lane_e = lane_now();
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
+        const int piece = lane & 3, rrow = lane >> 2;
+        char* wr = eb + srow(l31);
+        const int wsw = ((l31 >> 1) & 3) | ((l31 & 1) << 2);
+#pragma unroll
+        for (int st = 0; st < MI3 * NJ3; ++st) {
+            const int i = st / NJ3, j = st % NJ3;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                *(f32x4*)(wr + (((2 * g + lh) ^ wsw) << 4)) = v;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int row = 16 * p + rrow;
+                const int rsw = ((row >> 1) & 3) | ((row & 1) << 2);
+                const f32x4 v0 = *(const f32x4*)(eb + srow(row) + (((2 * piece) ^ rsw) << 4));
+                const f32x4 v1 = *(const f32x4*)(eb + srow(row) + (((2 * piece + 1) ^ rsw) << 4));
+                float* d = wst + (size_t)(wm * MI3 * 32 + 32 * i + row) * TBN3 + wn * NJ3 * 32 + 32 * j + 8 * piece;
+                *(f32x4*)d = v0;
+                *(f32x4*)(d + 4) = v1;
+            }
+        }
+        wait_lds();
+    };
+
     int gt = 0;                                                    // K tiles consumed so far (ring slot = gt & 1)
-    for (int cl = walk.local; cl < walk.count; cl += walk.stride) {
-        const int tile = walk.start + cl;
+    int cph = walk.local < walk.count ? 0 : 1, cl = walk.local;
+    for (; cph < 2; next_pos(cph, cl)) {
+        int tile, kb, ke;
+        item_decode(cph, cl, tile, kb, ke);
         const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
         const int mw = tm * TBM3 + wm * MI3 * 32;                  // first output row / column of this wave
         const int nw = tn * TBN3 + wn * NJ3 * 32;
@@ -434,7 +505,14 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
             idx_u = __builtin_amdgcn_readfirstlane(idx_u);
         }
         // accumulators start at bias (+ the wave's row of the row vector): loaded straight into them
-        {
+        if (SPLIT && cph == 1) {
+#pragma unroll
+            for (int i = 0; i < MI3; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ3; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        } else {
             const int lane_e = lane_now();
             const int lh_e = lane_e >> 5;
 #pragma unroll
@@ -451,7 +529,7 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
                 }
         }
         if (grp == 1) __builtin_amdgcn_s_barrier();                // second wave group runs one barrier behind
-        for (int kt = 0; kt < nk; ++kt, ++gt) {
+        for (int kt = kb; kt < ke; ++kt, ++gt) {
             const int bo = (gt & 1) * SLOT, bn = SLOT - bo;        // ring slot of this K tile / of the next one
             phase(IC<0>{}, bo, bn);
             phase(IC<1>{}, bo, bn);
@@ -463,7 +541,9 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
 
         // ---- epilogue (no barriers; scratch = this wave's blocks of the free ring plane) --------------------------------
         char* eb = smem + ((gt - 1) & 1) * SLOT + PLANE + wave * 1024;
-        if constexpr (GEGLU) {
+        if (SPLIT && cph == 1) {
+            epilogue_dump(acc, aux.ws + (size_t)blockIdx.x * (TBM3 * TBN3), eb);
+        } else if constexpr (GEGLU) {
             if (a.s_acc == 1.0f) epilogue_geglu(IC<1>{}, acc, mw, nw, eb);
             else epilogue_geglu(IC<0>{}, acc, mw, nw, eb);
         } else if constexpr (R1 || R2) {
@@ -489,6 +569,62 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
 
 typedef void (*igemm320_kern_t)(const mofa_igemm_args, const int, const int, const Aux);
 
+// split-K fix-up: out = act(s_acc * (sum over the K slices + bias + rowvec[idx(m)]) + s1 r1 + s2 r2) for the R remainder tiles,
+// one thread per 8 output columns of a row; the slices are added in slice order (deterministic)
+__global__ __launch_bounds__(256) void igemm320_fixup_kernel(const mofa_igemm_args a, const float* __restrict__ ws, const int tile0,
+                                                             const int nsplit, const int tilesN, const int R) {
+    constexpr int TBN = Geo<5>::TBN, PPR = TBN / 8, PPT = TBM3 * PPR;   // pieces per row / per tile
+    const long long total = (long long)R * PPT;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / PPT), rem = (int)(idx - (long long)r * PPT);
+        const int rr = rem / PPR, pc = rem - rr * PPR;
+        const int tile = tile0 + r, tm = tile / tilesN, tn = tile - tm * tilesN;
+        const int m = tm * TBM3 + rr, n = tn * TBN + pc * 8;
+        if (m >= a.M || n + 8 > a.N) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int sl = 0; sl < nsplit; ++sl) {
+            const float* q = ws + ((size_t)(r * nsplit + sl) * TBM3 + rr) * TBN + pc * 8;
+            const f32x4 p0 = *(const f32x4*)q, p1 = *(const f32x4*)(q + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+        }
+        if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a.bias[n + e];
+        }
+        if (a.rowvec) {
+            const int idx_rv = ((m / a.rv_div) * a.rv_mul + (m % a.rv_mod_in)) % a.rv_mod_out;
+            const float* q = a.rowvec + (size_t)idx_rv * a.N + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += q[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= a.s_acc;
+        if (a.r1) {
+            const f16x8 t = *(const f16x8*)((const f16*)a.r1 + (size_t)m * a.ldr1 + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a.s1 * (float)t[e];
+        }
+        if (a.r2) {
+            const f16x8 t = *(const f16x8*)((const f16*)a.r2 + (size_t)m * a.ldr2 + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a.s2 * (float)t[e];
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (a.act == MOFA_ACT_SILU) x = silu_f(x);
+            else if (a.act == MOFA_ACT_RELU) x = fmaxf(x, 0.0f);
+            else if (a.act == MOFA_ACT_GELU) x = gelu_erf_f(x);
+            o[e] = (f16)x;
+        }
+        *(f16x8*)((f16*)a.out + (size_t)m * a.ldo + n) = o;
+    }
+}
+
 }  // namespace
 
 // (kind 7 = row vector + two residuals does not fit the register file beside 160 accumulators and occurs nowhere in the
@@ -496,11 +632,35 @@ typedef void (*igemm320_kern_t)(const mofa_igemm_args, const int, const int, con
 static const igemm320_kern_t k_igemm320[7] = {igemm320_f16_kernel<0, 5>, igemm320_f16_kernel<1, 5>, igemm320_f16_kernel<2, 5>,
                                                igemm320_f16_kernel<3, 5>, igemm320_f16_kernel<4, 5>, igemm320_f16_kernel<5, 5>,
                                                igemm320_f16_kernel<6, 5>};
+static const igemm320_kern_t k_igemm320_split[7] = {
+    igemm320_f16_kernel<0, 5, true>, igemm320_f16_kernel<1, 5, true>, igemm320_f16_kernel<2, 5, true>, igemm320_f16_kernel<3, 5, true>,
+    igemm320_f16_kernel<4, 5, true>, igemm320_f16_kernel<5, 5, true>, igemm320_f16_kernel<6, 5, true>};
+
 int igemm320_init() {
     for (igemm320_kern_t k : k_igemm320)
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
+    for (igemm320_kern_t k : k_igemm320_split)
+        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
+            return MOFA_ELAUNCH;
     return MOFA_OK;
+}
+
+// Split-K for the tiles of a partial last round.  T tiles on n_cu persistent workgroups take ceil(T / n_cu) tile times although
+// the last round may hold only a few tiles (M = 460800, N = 320: 1800 tiles = 7 rounds + 8 tiles; M = 7200: 116 tiles on 256
+// CUs).  When a workspace is supplied, the R = T mod n_cu remainder tiles are cut into S K-slices (R * S <= n_cu work items of
+// nk / S K tiles each, fp32 partial tiles in the workspace) and a small fix-up kernel adds the slices in slice order and
+// applies the epilogue: the round shrinks to about 1 / S of a tile time.  Returns S (1 = no split).
+int igemm320_split(long long T, int nk, int n_cu, long long ws_bytes) {
+    const long long R = T % n_cu;
+    if (ws_bytes <= 0 || R == 0) return 1;
+    if (T > n_cu && R * 10 > (long long)n_cu * 6) return 1;   // a last round that is more than 60 % full stays whole
+    long long s = n_cu / R;
+    if (s > 8) s = 8;
+    if (s > nk / 2) s = nk / 2;                                // at least two K tiles per slice
+    const long long per = (long long)TBM3 * Geo<5>::TBN * 4;
+    while (s >= 2 && R * s * per > ws_bytes) --s;
+    return s >= 2 ? (int)s : 1;
 }
 
 // returns 0 launched, < 0 error, 1 not eligible (the caller falls back to another tile)
@@ -512,10 +672,32 @@ int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t st
     const int tilesM = cdiv(a->M, TBM3), tilesN = cdiv(a->N, tbn);
     const long long nt = (long long)tilesM * tilesN;
     if (nt > 0x7fffffffLL) return MOFA_EINVAL;
-    const Aux aux = igemm_pipe_aux(a, taps, tilesN);
-    int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
-    if (grid < 8) grid = 8;
-    hipLaunchKernelGGL(k_igemm320[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a, tilesN, (int)nt, aux);
+    Aux aux = igemm_pipe_aux(a, taps, tilesN);
+    const int nk = taps * (a->Cin / 64);
+    const bool ws_ok = a->workspace && (((size_t)a->workspace) & 15) == 0;
+    const int S = igemm320_split(nt, nk, n_cu, ws_ok ? a->workspace_bytes : 0);
+    if (S == 1) {
+        int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
+        if (grid < 8) grid = 8;
+        hipLaunchKernelGGL(k_igemm320[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a, tilesN, (int)nt, aux);
+        MOFA_CHECK_LAUNCH();
+        return MOFA_OK;
+    }
+    // one launch: the whole tiles of the full rounds, then one K slice of a remainder tile per workgroup; then the fix-up
+    const long long full = nt - nt % n_cu;
+    const int R = (int)(nt - full), items = R * S;
+    aux.nsplit = S;
+    aux.nsplit_d = fastdiv_make(S);
+    aux.tile0 = (int)full;
+    aux.nitems = items;
+    aux.ws = (float*)a->workspace;
+    int grid = full > 0 ? (n_cu / 8) * 8 : ((items + 7) / 8) * 8;
+    if (grid < items) return MOFA_EINVAL;                       // (R * S <= n_cu by construction)
+    hipLaunchKernelGGL(k_igemm320_split[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a, tilesN, (int)full, aux);
+    MOFA_CHECK_LAUNCH();
+    const long long pieces = (long long)R * TBM3 * (tbn / 8);
+    hipLaunchKernelGGL(igemm320_fixup_kernel, dim3((int)((pieces + 255) / 256)), dim3(256), 0, stream, *a,
+                       (const float*)a->workspace, (int)full, S, tilesN, R);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

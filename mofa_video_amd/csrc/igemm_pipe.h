@@ -17,6 +17,11 @@ struct Aux {                        // launch-invariant scalars computed by the 
     const void* xbase;              // base of the activation buffer descriptor
     unsigned x_bytes, w_bytes;      // extents of the two buffer descriptors
     unsigned long long* trace;      // VAR & 64: [workgroup][group][16] cycle sums
+    // split-K launches of igemm320.hip (remainder tiles of a partial last round): work item = (tile0 + item / nsplit, K slice
+    // item % nsplit); fp32 partial tiles [item][256][320] go to ws
+    FastDiv nsplit_d, kpt_d, ks_d;
+    int nsplit, tile0, nitems;
+    float* ws;
 };
 
 // One DMA row group = ONE packed register (Cursor::gx), decoded at every tap switch:
@@ -90,5 +95,12 @@ static inline Aux igemm_pipe_aux(const mofa_igemm_args* a, int taps, int tilesN)
     aux.x_bytes = (unsigned)(igemm8_rows_in(a) * a->ldx * 2 - (a->ldx - a->Cin) * 2);
     aux.w_bytes = (unsigned)((long long)a->N * taps * a->Cin * 2);
     aux.trace = nullptr;
+    aux.nsplit_d = fastdiv_make(1);
+    aux.kpt_d = fastdiv_make(a->Cin / 64);
+    aux.ks_d = fastdiv_make(a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize : 3) : 1);
+    aux.nsplit = 1;
+    aux.tile0 = 0;
+    aux.nitems = 0;
+    aux.ws = nullptr;
     return aux;
 }

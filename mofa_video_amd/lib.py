@@ -33,6 +33,7 @@ class IgemmArgs(C.Structure):
         ("act", C.c_int32),
         ("s_acc", C.c_float), ("s1", C.c_float), ("s2", C.c_float),
         ("dil", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
     ]
 
 

@@ -103,10 +103,24 @@ def convt3_geom(T, HW):
     return ConvGeom(L.MODE_CONVT3, T=T, HW=HW)
 
 
+IGEMM_WS_BYTES = 256 * 256 * 320 * 4     # split-K scratch: at most 256 partial tiles of 256 x 320 fp32 (84 MB)
+_igemm_ws = {}
+
+
+def igemm_workspace(device):
+    """the split-K scratch of the CURRENT stream on ``device`` (one per stream: launches of different streams overlap)"""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _igemm_ws.get(key)
+    if ws is None:
+        ws = _igemm_ws[key] = torch.empty(IGEMM_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, r2=None, s2=1.0,
-          act=L.ACT_NONE, s_acc=1.0, out=None, tile=None):
+          act=L.ACT_NONE, s_acc=1.0, out=None, tile=None, split_k=True):
     """out[m,n] = act(s_acc*(conv/gemm + bias + rowvec[idx(m)]) + s1*r1 + s2*r2).  See include/mofa_hip.h.
-    tile: one of lib.TILE_* to force the output tile (parity tests); default = ops.FORCE_TILE = the launcher's model."""
+    tile: one of lib.TILE_* to force the output tile (parity tests); default = ops.FORCE_TILE = the launcher's model.
+    split_k: hand the launcher this stream's scratch buffer so that it may split a partial last round of tiles along K."""
     lib = L.load()
     _chk(x, F16); _chk(w, F16)
     N, Ktot = w.shape
@@ -157,6 +171,11 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     a.act = act
     a.s_acc, a.s1, a.s2 = s_acc, s1, s2
     a.tile = FORCE_TILE if tile is None else tile
+    if split_k:
+        ws = igemm_workspace(x.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    else:
+        a.workspace, a.workspace_bytes = None, 0
     t0 = TIMER.start() if TIMER is not None else None
     L.check(lib.mofa_igemm_f16(C.byref(a), L.stream_ptr()), "mofa_igemm_f16")
     if t0 is not None:

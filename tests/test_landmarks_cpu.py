@@ -98,3 +98,24 @@ def test_pose_images_for_the_pipelines():
     pose = L.pose_images(kp, 256, 384)
     assert tuple(pose.shape) == (1, 3, 3, 256, 384) and pose.dtype == torch.float32
     assert float(pose.min()) == 0.0 and 0.5 < float(pose.max()) <= 250 / 255 + 1e-6
+
+
+def test_against_cv2_fixture():
+    """bit-exact comparison with real OpenCV output -- only where tests/golden/make_golden_cv2.py could run (a box with cv2);
+    this build image has none, so the pin is OPEN here and the test reports itself as skipped"""
+    import os
+
+    import pytest
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_golden_cv2.npz")
+    if not os.path.exists(path):
+        pytest.skip("no cv2 fixture (tests/golden/make_golden_cv2.py needs OpenCV): draw_landmarks is unpinned against cv2 itself")
+    G = np.load(path)
+    for (p1, p2), want in zip(G["seg_pts"], G["seg_imgs"]):
+        got = L.line(np.zeros((32, 32, 3)), tuple(int(v) for v in p1), tuple(int(v) for v in p2), (7, 8, 9), 2)
+        assert np.array_equal(got, want), (p1, p2)
+    for lm, want in zip(G["ldmk"], G["drawn"]):
+        assert np.array_equal(L.draw_landmarks(lm, 320, 320), want)
+    for want, drawn in zip(G["resized_576x1024"], G["drawn"]):
+        assert np.array_equal(L.resize_linear(drawn, 1024, 576), want)
+    for want, drawn in zip(G["resized_256x256"], G["drawn"]):
+        assert np.array_equal(L.resize_linear(drawn, 256, 256), want)
