@@ -657,7 +657,11 @@ int igemm320_split(long long T, int nk, int n_cu, long long ws_bytes) {
     if (T > n_cu && R * 10 > (long long)n_cu * 6) return 1;   // a last round that is more than 60 % full stays whole
     long long s = n_cu / R;
     if (s > 8) s = 8;
-    if (s > nk / 2) s = nk / 2;                                // at least two K tiles per slice
+    if (s > nk / 8) s = nk / 8;                                // at least eight K tiles per slice, and ...
+    // ... only where it pays: a slice saves (1 - 1 / S) of a tile's K loop (about 2 us per K tile) but costs the partial-tile
+    // dump and the fix-up launch (about 25 us; profiles/r03b_kernel_stats_bench.md: splitting the shallow-K launches of the
+    // clip -- 5 100 of 12 012 -- made it 4 % SLOWER)
+    if (s >= 2 && 2.0 * nk * (1.0 - 1.0 / (double)s) < 50.0) s = 1;
     const long long per = (long long)TBM3 * Geo<5>::TBN * 4;
     while (s >= 2 && R * s * per > ws_bytes) --s;
     return s >= 2 ? (int)s : 1;
