@@ -49,6 +49,9 @@ int mofa_version(void);
  * and the adapter's own convs (models/svdxt_featureflow_forward_controlnet_s2d_fixcmp_norefine.py:66-155).
  * ---------------------------------------------------------------------------------------- */
 enum { MOFA_MODE_PLAIN = 0, MOFA_MODE_CONV3X3 = 1, MOFA_MODE_CONVT3 = 2 };   /* CONV3X3 = k x k conv, k = ksize (1, 3, 5 or 7) */
+/* MOFA_ACT_GEGLU_PAIR: W holds the GEGLU projection with value and gate rows INTERLEAVED IN BLOCKS OF 16 (rows 32 b .. 32 b + 15 =
+ * value rows of outputs 16 b .. 16 b + 15, rows 32 b + 16 .. 32 b + 31 = their gate rows; bias alike): out[m][16 b + c] =
+ * s_acc * val * gelu(s_acc * gate), N / 2 output columns (diffusers GEGLU, erf GELU).  mofa_video_amd/weights.py packs it. */
 enum { MOFA_ACT_NONE = 0, MOFA_ACT_SILU = 1, MOFA_ACT_GEGLU_PAIR = 2, MOFA_ACT_RELU = 3,
        MOFA_ACT_GELU = 4 /* exact (erf) GELU: CLIP vision MLP, transformers CLIPMLP with hidden_act = "gelu" */ };
 

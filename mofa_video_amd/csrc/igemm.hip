@@ -70,10 +70,12 @@ __device__ __forceinline__ void load_bias(const mofa_igemm_args& a, int ncol0, i
     b[0] = z; b[1] = z; b[2] = z; b[3] = z;
     if (!a.bias) return;
     if (GEGLU) {
-        int nv = ncol0 + (lane & 3) * 8;                           // N is a multiple of 64 here
+        // value / gate rows interleaved in blocks of 16 (weights.interleave_geglu): this lane's 8 outputs (lane & 3) * 8 .. + 7
+        // of the wave's 32 have their value columns at 32 t + o, their gate columns 16 further (t = tile, o = 0 or 8)
+        int nv = ncol0 + ((lane & 3) >> 1) * 32 + (lane & 1) * 8;  // N is a multiple of 64 here
         nv = nv < a.N ? nv : 0;                                    // columns beyond N are never stored
         b[0] = *(const f32x4*)(a.bias + nv); b[1] = *(const f32x4*)(a.bias + nv + 4);
-        b[2] = *(const f32x4*)(a.bias + nv + 32); b[3] = *(const f32x4*)(a.bias + nv + 36);
+        b[2] = *(const f32x4*)(a.bias + nv + 16); b[3] = *(const f32x4*)(a.bias + nv + 20);
     } else {
         const int n = ncol0 + (lane & 7) * 8;
         const int n_lo = n + 4 <= a.N ? n : 0;                     // columns beyond N are never stored
@@ -195,15 +197,18 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
                 const int row = p * RPP + lrow;
                 const int m = mrow0 + i * 32 + row;
                 float v[8];
+                // (GEGLU: value chunks of outputs 8 lc .. 8 lc + 7 = 16-byte chunks 8 t + 2 o, + 1 of the 64-column slab row,
+                //  t = lc >> 1, o = lc & 1; the gate chunks follow 4 chunks = 16 columns later)
+                const int vch = GEGLU ? 8 * (lc >> 1) + 2 * (lc & 1) : 2 * lc;
                 {
-                    const f32x4 v0 = *(const f32x4*)(slab + slab_off(row, 2 * lc));
-                    const f32x4 v1 = *(const f32x4*)(slab + slab_off(row, 2 * lc + 1));
+                    const f32x4 v0 = *(const f32x4*)(slab + slab_off(row, vch));
+                    const f32x4 v1 = *(const f32x4*)(slab + slab_off(row, vch + 1));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
                 }
                 if (GEGLU) {
-                    const f32x4 g0 = *(const f32x4*)(slab + slab_off(row, 8 + 2 * lc));
-                    const f32x4 g1 = *(const f32x4*)(slab + slab_off(row, 9 + 2 * lc));
+                    const f32x4 g0 = *(const f32x4*)(slab + slab_off(row, vch + 4));
+                    const f32x4 g1 = *(const f32x4*)(slab + slab_off(row, vch + 5));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[e] = saccv * (v[e] + bias[0][e]) * gelu_erf_f(saccv * (g0[e] + bias[2][e]));
@@ -540,15 +545,20 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
             const double cost = (double)((t + n_cu - 1) / n_cu) * 256 * 256 * 0.62 * (1.0 + epi8[kind] / nk);
             if (cost < best) { best = cost; choice = MOFA_TILE_256X256; }
         }
-        if (kind != 8) {
+        if (kind != 7) {
             // 256x320 (igemm320.hip): 0.58 per area (10 % less LDS-DMA, 7 % fewer fragment reads per flop than 256x256); its
-            // epilogues move 25 % more outputs per tile through a smaller scratch
-            static const double epi320[8] = {3.0, 10.0, 10.0, 11.5, 3.5, 10.5, 10.5, 12.0};   // fitted: profiles/r03_igemm_tiles_bench.log
+            // epilogues move 25 % more outputs per tile
+            static const double epi320[9] = {3.0, 10.0, 10.0, 11.5, 3.5, 10.5, 10.5, 12.0, 5.0};   // fitted: profiles/r03_igemm_tiles_bench.log
             const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 320);
             // a partial last round split along K (igemm320_split) costs 1 / S of a round + the fix-up pass
-            const int S = igemm320_split(t, (int)nk, n_cu, a->workspace ? a->workspace_bytes : 0);
+            const int S = kind == 8 ? 1 : igemm320_split(t, (int)nk, n_cu, a->workspace ? a->workspace_bytes : 0);
             const double rounds = S > 1 ? (double)(t / n_cu) + 1.0 / S + 0.12 : (double)((t + n_cu - 1) / n_cu);
-            const double cost = rounds * 256 * 320 * 0.58 * (1.0 + epi320[kind] / nk);
+            // wide outputs (many column tiles: every CU of an XCD streams its own weight tile through the fabric) run
+            // relatively slower on this tile than on 256x256 (profiles/r03_igemm_tiles_bench_geglu320.log: N = 3840 / 10240
+            // 7 / 15 % behind): +2 % per column tile beyond 6, at most +25 %
+            const int tn320 = cdiv(a->N, 320);
+            const double wide = 1.0 + (tn320 > 6 ? (tn320 - 6 > 12 ? 0.25 : 0.02 * (tn320 - 6)) : 0.0);
+            const double cost = rounds * 256 * 320 * 0.58 * wide * (1.0 + epi320[kind] / nk);
             if (cost < best) { best = cost; choice = MOFA_TILE_256X320; }
         }
     }

@@ -25,7 +25,7 @@
 //     no scratch image of it (the 2 KB scratch is one 32 x 32 fp16 / 16 x 32 fp32 transpose).
 //   * epilogues: no residual, uniform row vector -> activation in the fragment layout, fp16, 32 x 32 transposes, 16-byte
 //     stores; residuals / per-row row vector -> 16 x 32 fp32 transposes (half the lanes write at a time), the sum rounded once.
-// Kinds: plain (+ SiLU / ReLU / GELU), row vector, one or two residuals (the GEGLU pair kind stays on the 256x256 kernel).
+// Kinds: plain (+ SiLU / ReLU / GELU), row vector, one or two residuals, GEGLU pair (value / gate rows interleaved by 16).
 #include "igemm_common.h"
 #include "igemm_pipe.h"
 
@@ -69,7 +69,6 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
                                                               const Aux aux) {
     constexpr bool R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0, RV = (EPI & EPI_RV) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
     constexpr int TBN3 = Geo<NJ3>::TBN, PLANE = Geo<NJ3>::PLANE, SLOT = Geo<NJ3>::SLOT, LOOKAHEAD3 = Geo<NJ3>::LOOKAHEAD;
-    static_assert(!GEGLU || NJ3 == 4, "the GEGLU pair kind needs an even number of column tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // the ONLY shared object
     TileWalk walk;
     walk.init(ntiles);
@@ -334,9 +333,11 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         }
         wait_lds();
     };
-    // ---- GEGLU pair kind (NJ = 4): value tiles j = 0, 2 and gate tiles j = 1, 3 (weight rows interleaved in blocks of 32 at
-    //      load time) give 64 output columns per row and wave: one 32 x 64 fp16 transpose and four whole-line stores per
-    //      accumulator row block.  out = s_acc * val * gelu(s_acc * gate), erf GELU as x * Phi(x) (common.h) -------------------
+    // ---- GEGLU pair kind: the weight rows are interleaved in blocks of 16 (weights.interleave_geglu), so accumulator tile j
+    //      holds the value columns of outputs 16 j .. 16 j + 15 in registers 0-7 and the matching gate columns in registers
+    //      8-15 of the SAME lane: the product is lane-local and a wave's NJ tiles give 16 NJ output columns (80 of the tile's
+    //      160).  out = s_acc * val * gelu(s_acc * gate), erf GELU as x * Phi(x) (common.h).  Tiles 0-3 (64 output columns)
+    //      go through one 32 x 64 fp16 transpose and whole 128-byte row pieces, tile 4 (16 columns) through a second one ------
     auto epilogue_geglu = [&](auto s1c, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
         constexpr bool SACC1 = decltype(s1c)::v != 0;              // s_acc == 1: the multiplies drop out
         const int lane_e = lane_now();
@@ -344,24 +345,27 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         f16* out = (f16*)a.out;
         float saccv = a.s_acc;
         asm volatile("" : "+v"(saccv));
-        const int nout = a.N / 2;
+        const int nout = a.N / 2, no0 = nw / 2;                    // first output column of this wave
         char* wr = eb + srow(l31);
         const int wsw = (l31 >> 1) & 7, wpar = l31 & 1;
+        auto product = [&](int i, int j, int g) __attribute__((always_inline)) -> f16x4 {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float val = acc[i][j][4 * g + e], gate = acc[i][j][8 + 4 * g + e];
+                if constexpr (SACC1) o[e] = (f16)(val * (gate * gelu_phi_f(gate)));
+                else o[e] = (f16)(saccv * val * gelu_erf_f(saccv * gate));
+            }
+            return o;
+        };
 #pragma unroll
         for (int i = 0; i < MI3; ++i) {
 #pragma unroll
-            for (int jj = 0; jj < NJ3 / 2; ++jj)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float val = acc[i][2 * jj][4 * g + e], gate = acc[i][2 * jj + 1][4 * g + e];
-                        if constexpr (SACC1) o[e] = (f16)(val * (gate * gelu_phi_f(gate)));
-                        else o[e] = (f16)(saccv * val * gelu_erf_f(saccv * gate));
-                    }
-                    const int c8 = 8 * jj + 2 * g + lh;
-                    *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+                for (int g = 0; g < 2; ++g) {
+                    const int c8 = 4 * j + 2 * g + lh;             // 8-byte chunk (4 columns) of the 64-column row
+                    *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = product(i, j, g);
                 }
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -369,7 +373,20 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
                 const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
                 f16x8 o = v;
                 if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
-                const int mr = mw + 32 * i + row, n = nw / 2 + 8 * blk;
+                const int mr = mw + 32 * i + row, n = no0 + 8 * blk;
+                if (mr < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
+            }
+            if constexpr (NJ3 == 5) {                              // tile 4: 16 columns per row
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int c8 = 2 * g + lh;
+                    *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = product(i, 4, g);
+                }
+                const int row = lane >> 1, blk = lane & 1;
+                const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                f16x8 o = v;
+                if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                const int mr = mw + 32 * i + row, n = no0 + 64 + 8 * blk;
                 if (mr < a.M && n + 8 <= nout) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
             }
         }
@@ -629,16 +646,16 @@ __global__ __launch_bounds__(256) void igemm320_fixup_kernel(const mofa_igemm_ar
 
 // (kind 7 = row vector + two residuals does not fit the register file beside 160 accumulators and occurs nowhere in the
 // model graph: it runs on the 4-wave tiles)
-static const igemm320_kern_t k_igemm320[7] = {igemm320_f16_kernel<0, 5>, igemm320_f16_kernel<1, 5>, igemm320_f16_kernel<2, 5>,
+static const igemm320_kern_t k_igemm320[9] = {igemm320_f16_kernel<0, 5>, igemm320_f16_kernel<1, 5>, igemm320_f16_kernel<2, 5>,
                                                igemm320_f16_kernel<3, 5>, igemm320_f16_kernel<4, 5>, igemm320_f16_kernel<5, 5>,
-                                               igemm320_f16_kernel<6, 5>};
+                                               igemm320_f16_kernel<6, 5>, nullptr, igemm320_f16_kernel<8, 5>};
 static const igemm320_kern_t k_igemm320_split[7] = {
     igemm320_f16_kernel<0, 5, true>, igemm320_f16_kernel<1, 5, true>, igemm320_f16_kernel<2, 5, true>, igemm320_f16_kernel<3, 5, true>,
     igemm320_f16_kernel<4, 5, true>, igemm320_f16_kernel<5, 5, true>, igemm320_f16_kernel<6, 5, true>};
 
 int igemm320_init() {
     for (igemm320_kern_t k : k_igemm320)
-        if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
+        if (k && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
     for (igemm320_kern_t k : k_igemm320_split)
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
@@ -670,7 +687,7 @@ int igemm320_split(long long T, int nk, int n_cu, long long ws_bytes) {
 // returns 0 launched, < 0 error, 1 not eligible (the caller falls back to another tile)
 int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stream) {
     const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
-    if (kind >= 7 || !igemm_pipe_eligible(a, kind, (long long)taps * a->Cin)) return 1;
+    if (kind == 7 || !igemm_pipe_eligible(a, kind, (long long)taps * a->Cin)) return 1;
     constexpr int tbn = Geo<5>::TBN;
     if ((long long)(a->N + tbn) * taps * a->Cin * 2 >= 0x7ff00000LL) return 1;   // unclamped W row offsets stay below W_DEAD
     const int tilesM = cdiv(a->M, TBM3), tilesN = cdiv(a->N, tbn);
@@ -679,7 +696,7 @@ int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t st
     Aux aux = igemm_pipe_aux(a, taps, tilesN);
     const int nk = taps * (a->Cin / 64);
     const bool ws_ok = a->workspace && (((size_t)a->workspace) & 15) == 0;
-    const int S = igemm320_split(nt, nk, n_cu, ws_ok ? a->workspace_bytes : 0);
+    const int S = kind == 8 ? 1 : igemm320_split(nt, nk, n_cu, ws_ok ? a->workspace_bytes : 0);   // (the fix-up has no GEGLU form)
     if (S == 1) {
         int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
         if (grid < 8) grid = 8;

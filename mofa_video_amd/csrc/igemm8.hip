@@ -369,13 +369,16 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
         for (int i = 0; i < MI; ++i) {
             const int m = mw + 32 * i + l31;
             if constexpr (GEGLU) {
-                // value tile j = 0, gate tile j = 1 (weight rows interleaved in blocks of 32 at load time)
+                // weight rows are interleaved in blocks of 16 at load time (weights.interleave_geglu): accumulator tile j holds
+                // the value columns of outputs 16 j .. 16 j + 15 in registers 0-7 and their gate columns in registers 8-15 of
+                // the same lane; output group g (columns 8 g + 4 lh + e of the wave's 32) = tile g >> 1, half g & 1
                 f16x4 o[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float val = acc[i][0][4 * g + e] + bv[0][g][e], gate = acc[i][1][4 * g + e] + bv[1][g][e];
+                        const float val = acc[i][g >> 1][4 * (g & 1) + e] + bv[g >> 1][g & 1][e];
+                        const float gate = acc[i][g >> 1][8 + 4 * (g & 1) + e] + bv[g >> 1][2 + (g & 1)][e];
                         if constexpr (SACC1) o[g][e] = (f16)(val * (gate * gelu_phi_f(gate)));
                         else o[g][e] = (f16)(saccv * val * gelu_erf_f(saccv * gate));
                     }

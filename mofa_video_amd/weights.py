@@ -46,13 +46,15 @@ def pad_rows(w, mult=4):
 
 
 def interleave_geglu(w, b):
-    """GEGLU projection [8C, K]: rows [0,4C) = value, [4C,8C) = gate.  Interleave in blocks of 32 rows
-    (value block j, gate block j) so one wave of the GEMM holds matching value/gate columns and the
-    x * gelu(gate) product is formed in the epilogue (MOFA_ACT_GEGLU_PAIR)."""
+    """GEGLU projection [8C, K]: rows [0,4C) = value, [4C,8C) = gate.  Interleave in blocks of 16 rows (value block j, gate
+    block j): every 32-row MFMA tile of the GEMM then holds 16 value columns and the 16 matching gate columns, and in the
+    32x32 accumulator layout (register r <-> column 8 (r >> 2) + 4 (lane >> 5) + (r & 3)) registers r and r + 8 of ONE lane are
+    a value / gate pair -- the x * gelu(gate) product is formed lane-locally in the epilogue (MOFA_ACT_GEGLU_PAIR) on every
+    tile shape, whatever the number of column tiles a wave owns (the 256x320 tile gives a wave five)."""
     n2 = w.shape[0]
     ch = n2 // 2
-    assert ch % 32 == 0
-    idx = torch.arange(n2).reshape(2, ch // 32, 32).permute(1, 0, 2).reshape(-1)
+    assert ch % 16 == 0
+    idx = torch.arange(n2).reshape(2, ch // 16, 16).permute(1, 0, 2).reshape(-1)
     return w[idx].contiguous(), (b[idx].contiguous() if b is not None else None)
 
 

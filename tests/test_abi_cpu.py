@@ -85,7 +85,8 @@ def test_weight_packing():
     Ch = 64
     wg = torch.arange(2 * Ch, dtype=torch.float32).reshape(2 * Ch, 1)
     wi, bi = interleave_geglu(wg, wg[:, 0])
-    assert wi[:32, 0].tolist() == list(range(32)) and wi[32:64, 0].tolist() == list(range(Ch, Ch + 32))
+    assert wi[:16, 0].tolist() == list(range(16)) and wi[16:32, 0].tolist() == list(range(Ch, Ch + 16))
+    assert wi[32:48, 0].tolist() == list(range(16, 32))
     assert torch.equal(wi[:, 0], bi)
 
 

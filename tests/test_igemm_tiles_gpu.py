@@ -107,7 +107,7 @@ def test_plain_gemm_every_tile_every_kind(ops, tile, kind):
     _close(out, apply(x.float() @ w.float().t()), what=f"plain {tile} {kind}")
 
 
-@pytest.mark.parametrize("tile", [t for t in TILES if t != "256x320"])      # (the GEGLU pair kind has no 256x320 form)
+@pytest.mark.parametrize("tile", list(TILES))
 def test_geglu_pair_every_tile(ops, tile):
     from mofa_video_amd.weights import interleave_geglu
     M, Cc = 33000, 128                                  # N = 8 C = 1024: 129 x 4 tiles of 256x256
@@ -195,8 +195,6 @@ def test_forced_phase_pipelined_tile_rejects_unaligned_rows(ops):
     for t in PIPE:
         with pytest.raises(MofaHipError):
             ops.igemm(x, w, tile=TILES[t])
-    with pytest.raises(MofaHipError):                    # the GEGLU pair kind is refused by a forced 256x320
-        ops.igemm(_h(300, 64, seed=1), _h(128, 64, seed=2), act=2, tile=TILES["256x320"])
 
 
 # ---- the bench's own problem shapes (BASELINE config 2), reference in row chunks on the GPU ------------------------------
@@ -204,7 +202,7 @@ def _chunked_ref(x, w, rows=32768):
     return torch.cat([x[i:i + rows].float() @ w.float().t() for i in range(0, x.shape[0], rows)])
 
 
-@pytest.mark.parametrize("tile", ["192x128", "256x256"])
+@pytest.mark.parametrize("tile", ["192x128", "256x256", "256x320"])
 def test_bench_shape_geglu_l0(ops, tile):
     from mofa_video_amd.weights import interleave_geglu
     M, Cc = 460800, 320
@@ -219,7 +217,7 @@ def test_bench_shape_geglu_l0(ops, tile):
         _close(out[i:i + 65536], h[:, :4 * Cc] * F.gelu(h[:, 4 * Cc:]), what=f"bench GEGLU L0 {tile} rows {i}")
 
 
-@pytest.mark.parametrize("tile", ["192x128", "256x256"])
+@pytest.mark.parametrize("tile", ["192x128", "256x256", "256x320"])
 def test_bench_shape_geglu_l2(ops, tile):
     from mofa_video_amd.weights import interleave_geglu
     M, Cc = 28800, 1280
