@@ -336,8 +336,22 @@ class TransformerSpatioTemporal:
             # buffer, one all_gather_into_tensor (asynchronous, RCCL's stream) fills the other slots while the Q
             # projection runs, and the attention kernel masks the padding frames of the shorter shards.
             Cc, par = self.C, c.par
-            fn = self.tnorm1(f)
-            if par.kv_slots <= 32 and par.kv_inplace:
+            if par.kv_slots <= 32 and par.kv_inplace and par.gather_hidden:
+                # gather the NORMED HIDDEN tokens (C columns) instead of K|V (2C): half the bytes over xGMI; every rank then
+                # projects K|V for all key slots itself (4 x the rows of a 2C x C GEMM at 4 frame shards: ~0.1 ms at level 0
+                # against ~1 ms of transfer saved).  LayerNorm writes this shard's slot of the gather buffer in place; the
+                # padding slots of shorter shards hold whatever the allocator left -- their K|V rows are computed but masked,
+                # never read by the attention kernel.
+                hid, own = par.kv_buffer(HW, Cc, f.device)
+                fn = self.tnorm1(f, out=own)
+                work = par.kv_gather_begin(hid, HW)
+                q = self.tattn1.q(fn)
+                work.wait()
+                kv = ops.igemm(hid, self.tattn1.wqkv[Cc:])
+                a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.kv_slots, HW, self.heads,
+                                      head_dim=self.tattn1.head_dim, Tq=T, key_mask=par.kv_mask)
+            elif par.kv_slots <= 32 and par.kv_inplace:
+                fn = self.tnorm1(f)
                 kv, own = par.kv_buffer(HW, 2 * Cc, fn.device)
                 self.tattn1.kv_into(fn, own)
                 work = par.kv_gather_begin(kv, HW)
@@ -347,6 +361,7 @@ class TransformerSpatioTemporal:
                                       head_dim=self.tattn1.head_dim, Tq=T, key_mask=par.kv_mask)
             else:   # more than 32 key slots after padding (e.g. 31 frames over 3 shards), or the in-place path failed
                     # its self-check on this transport (parallel.FrameParallel.self_check): compact to T_full frames
+                fn = self.tnorm1(f)
                 q, k, v = self.tattn1.qkv(fn)
                 kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
                 ops.copy2d(k, kv[:, :Cc])

@@ -6,6 +6,7 @@ fine).  PyTorch only provides device memory and the stream here; all arithmetic 
 libmofa_hip.so.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -105,6 +106,8 @@ def convt3_geom(T, HW):
 
 IGEMM_WS_BYTES = 256 * 256 * 320 * 4     # split-K scratch: at most 256 partial tiles of 256 x 320 fp32 (84 MB)
 _igemm_ws = {}
+_igemm_ws_lock = threading.Lock()         # threads that share a stream (the virtual-rank tests) share its scratch: the split
+                                          # launch and its fix-up must be enqueued back to back
 
 
 def igemm_workspace(device):
@@ -177,7 +180,12 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     else:
         a.workspace, a.workspace_bytes = None, 0
     t0 = TIMER.start() if TIMER is not None else None
-    L.check(lib.mofa_igemm_f16(C.byref(a), L.stream_ptr()), "mofa_igemm_f16")
+    if split_k:
+        with _igemm_ws_lock:
+            rc = lib.mofa_igemm_f16(C.byref(a), L.stream_ptr())
+    else:
+        rc = lib.mofa_igemm_f16(C.byref(a), L.stream_ptr())
+    L.check(rc, "mofa_igemm_f16")
     if t0 is not None:
         TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot,
                    tag=(geom.mode, geom.stride, geom.up, M, N, Ktot, act))

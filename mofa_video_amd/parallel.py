@@ -6,10 +6,10 @@ Layout for N ranks (N in 1, 2, 4, 8, ...):  2-way CFG x (N/2)-way frames.
 Weights are replicated.  Exchanges inside one denoise step (RCCL over xGMI through torch.distributed):
     * temporal GroupNorm (statistics span all T frames): all-reduce of fp64 [32][2] partial sums   (frame group)
     * temporal (3,1,1) convolution: one halo frame from each neighbour shard (batched p2p)        (frame group)
-    * temporal self-attention: ONE all_gather_into_tensor of the K|V token columns into a preallocated
-      [frame_ranks x T_max frames] buffer (the K|V projection writes this rank's slot in place, the collective runs
-      asynchronously under the Q projection, and the attention kernel masks the padding frames of uneven shards --
-      no pad / concat / compaction copies)                                                          (frame group)
+    * temporal self-attention: ONE all_gather_into_tensor of the normed hidden tokens (C columns; r02 gathered K|V = 2C) into
+      a preallocated [frame_ranks x T_max frames] buffer (the LayerNorm writes this rank's slot in place, the collective runs
+      asynchronously under the Q projection, every rank then projects K|V for all key slots, and the attention kernel masks
+      the padding frames of uneven shards -- no pad / concat / compaction copies)                   (frame group)
     * CFG combine: the two halves of one frame shard swap their noise predictions                 (pair group)
 and once per clip: all-gather of the final latents before the VAE decode, whose chunks are independent and are
 dealt round-robin to ALL ranks.  Everything per-frame (2-D convs, spatial norms/attention, FFs, the adapter warps,
@@ -213,6 +213,7 @@ class FrameParallel:
         self.T_full, self.T_loc, self.f0, self.f1 = layout.T, layout.T_loc, layout.f0, layout.f1
         self.p2p = p2p and isinstance(comm, TorchComm)
         self.kv_inplace = True      # temporal attention K|V: in-place asynchronous all_gather_into_tensor (else: compacting gather)
+        self.gather_hidden = True   # ... of the normed hidden tokens (C columns; K|V projected after the gather) instead of K|V (2C)
 
     def self_check(self, device):
         """Runs the two transport-specific fast paths once on small known data -- the in-place asynchronous

@@ -1,8 +1,8 @@
-# usage (on the GPU box, from gpurun):  bash tools/profile_round.sh [tag]      (default tag r01e)
-# kernel statistics of one bench clip, the three PMC passes (separate runs, --kernel-trace only), the igemm HBM traffic /
+# usage (on the GPU box, from gpurun):  bash tools/profile_round.sh [tag]
+# kernel statistics of one bench clip, the three PMC passes (separate runs, --kernel-trace only), the igemm fabric traffic /
 # MFMA-busy summary derived from them, then the default bench line (which cites that summary).  Everything lands in
 # gpurun_out/<tag>_*; copy what should be judged into profiles/.
-TAG=${1:-r01e}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/st -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.log 2>&1
