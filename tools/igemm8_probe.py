@@ -1,6 +1,7 @@
 """K-loop probe of the phase-pipelined 256x256 implicit-GEMM tile (csrc/igemm8.hip): times the diagnostic build variants
-(template parameter VAR, selected through the library's internal hook mofa_igemm8_set_probe) on plain GEMMs with random
-data, interleaved rounds in one process, and prints the per-segment cycle trace of variant 64.
+(template parameter VAR, selected through the hook mofa_igemm8_set_probe) on plain GEMMs with random data, interleaved rounds
+in one process, and prints the per-segment cycle trace of variant 64.  The variants and the hook are NOT in the product
+library: this tool builds and loads tools/libmofa_hip_probe.so (the same sources with -DMOFA_PROBE; `_build.build(probe=True)`).
 
     python tools/igemm8_probe.py [--shapes 4096x4096x4096,...] [--vars 0,1,2,...]
 """
@@ -12,7 +13,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mofa_video_amd import lib, ops  # noqa: E402
+from mofa_video_amd import _build, lib, ops  # noqa: E402
+
+lib.LIB_PATH = os.path.abspath(_build.build(probe=True))   # the probe library stands in for libmofa_hip.so in this process
 
 NAMES = {0: "shipped", 1: "no stagger", 2: "no setprio", 3: "no stagger, no setprio", 4: "DMA issue before reads", 8: "no vmcnt wait (wrong)",
          16: "no DMA in loop (wrong)", 32: "no fragment reads (wrong)", 48: "MFMA + barriers only (wrong)", 64: "traced",
