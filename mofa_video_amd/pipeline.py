@@ -116,8 +116,15 @@ class FlowControlNetPipeline:
             raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
 
     def _check_call(self, batch_size, num_videos_per_prompt, max_guidance_scale, frames_per_forward):
+        """The reference repeats the image embeddings / latents by ``num_videos_per_prompt`` (pipeline.py:130-131, :162) and draws
+        ``batch_size * num_videos_per_prompt`` latents (:377-387), but doubles ``controlnet_condition`` / ``controlnet_flow`` only for
+        CFG (:392-396) and builds ``added_time_ids`` for ``batch_size`` (:430-440): with anything but 1 x 1 its own
+        ``FlowControlNet.forward`` / ``add_embedding`` reshape fail on the batch mismatch, and every entry point calls it with
+        1 x 1.  One clip per call therefore IS the reference's behaviour; several videos = several calls with different
+        generators / latents."""
         if batch_size != 1 or num_videos_per_prompt != 1:
-            raise ValueError("one clip per call (as every reference entry point does)")
+            raise ValueError("one clip per call (batch_size = num_videos_per_prompt = 1, the only combination the reference's "
+                             "own forward accepts: its controlnet_condition / added_time_ids are not repeated)")
         if not max_guidance_scale > 1.0:
             raise ValueError("the reference pipeline is only well-defined with classifier-free guidance on")
         if frames_per_forward > MAX_TEMPORAL_FRAMES:
