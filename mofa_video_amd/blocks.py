@@ -127,9 +127,41 @@ class GegluFF:
         self.w1, self.b1 = s.dev(pack_linear(w)), s.dev(f32(b))
         self.out = Linear(s.sub("net.2"))
 
+    # rows per pass when the 4C-wide hidden tensor of the whole batch would not fit the 256 MB Infinity Cache: the projection
+    # and net.2 then run chunk by chunk (<= 160 MB of hidden rows each, whole 256-row tiles) so that net.2 reads its operand from
+    # the cache instead of HBM.  Same kernels on the same tiles: bit-identical.  Level 0 of the bench (460 800 x 1280 = 1.18 GB):
+    # 1 556 -> 1 465 us per feed-forward (tools/ff_chunk_probe.py); no gain at level 1 (590 MB), so only above 768 MB.
+    CHUNK_ABOVE_BYTES = 768 << 20
+    CHUNK_BYTES = 160 << 20
+
     def __call__(self, x, **epilogue):
-        h = ops.igemm(x, self.w1, self.b1, act=L.ACT_GEGLU_PAIR)
-        return self.out(h, **epilogue)
+        M, hid = x.shape[0], self.w1.shape[0] // 2
+        rowvec, rv = epilogue.get("rowvec"), epilogue.get("rv", (1, 1, 1, BIG))
+        unit = 256
+        if rowvec is not None:                                   # chunks must start where the row-vector index pattern restarts
+            unit = 256 * rv[0] // math.gcd(256, rv[0]) if rv[2] == 1 else 0
+        rows = (self.CHUNK_BYTES // (hid * 2)) // unit * unit if unit else 0
+        if M * hid * 2 <= self.CHUNK_ABOVE_BYTES or rows <= 0 or rows >= M:
+            h = ops.igemm(x, self.w1, self.b1, act=L.ACT_GEGLU_PAIR)
+            return self.out(h, **epilogue)
+        out = torch.empty((M, self.out.n_real), dtype=torch.float16, device=x.device)
+        h = torch.empty((rows, hid), dtype=torch.float16, device=x.device)
+        for m0 in range(0, M, rows):
+            m1 = min(m0 + rows, M)
+            hh = ops.igemm(x[m0:m1], self.w1, self.b1, act=L.ACT_GEGLU_PAIR, out=h[:m1 - m0])
+            kw = {k: (v[m0:m1] if k in ("r1", "r2") and v is not None else v) for k, v in epilogue.items()}
+            if rowvec is not None:
+                # idx(m0 + m) = (idx(m0) + idx(m)) % mod_out when m0 is a multiple of rv_div (and rv_mod_in == 1): the chunk
+                # reads a table rotated / offset by idx(m0)
+                i0 = (m0 // rv[0]) * rv[1]
+                if rv[3] >= BIG:
+                    kw["rowvec"] = rowvec[i0:]
+                else:
+                    assert rowvec.shape[0] == rv[3]
+                    i0 %= rv[3]
+                    kw["rowvec"] = torch.cat([rowvec[i0:], rowvec[:i0]], 0).contiguous() if i0 else rowvec
+            self.out(hh, out=out[m0:m1], **kw)
+        return out
 
 
 def _sigmoid(v):
