@@ -292,6 +292,48 @@ def test_split_k_remainder_tiles_256x320(ops, M, N, K, kind):
     assert torch.equal(split, ops.igemm(x, w, bias, tile=TILES["256x320"], split_k=True, **kw))
 
 
+@pytest.mark.parametrize("mode", ["conv3x3", "conv3x3_s2", "convt3", "convt3_halo"])
+def test_split_k_convolutions_slices_start_inside_a_tap(ops, mode):
+    """split-K on the implicit-GEMM convolutions: the K slices of a remainder tile start in the MIDDLE of a tap (9 or 3 taps of
+    Cin / 64 K tiles each, cut into 4-6 slices), so the producer cursors set up (tap, K tile within the tap) from the slice start"""
+    from mofa_video_amd.weights import pack_conv3d_t3, pack_conv3x3
+    g = torch.Generator().manual_seed(70)
+    if mode.startswith("conv3x3"):
+        n, Cin, Cout, H, W = 6, 256, 320, 37, 53              # K = 2304 = 36 K tiles, 4 per tap
+        stride = 2 if mode.endswith("s2") else 1
+        x = torch.randn(n, Cin, H, W, generator=g).half()
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03).half()
+        xt = x.permute(0, 2, 3, 1).reshape(n * H * W, Cin).contiguous().to(DEV)
+        geom = ops.conv3x3_geom(H, W, stride=stride)
+        M = n * geom.Hout * geom.Wout
+        bias, kw, apply = _epilogue("r1rvu", M, Cout)
+        wk = pack_conv3x3(w).to(DEV)
+        ref = F.conv2d(x.float().to(DEV), w.float().to(DEV), None, stride=stride, padding=1).permute(0, 2, 3, 1).reshape(-1, Cout)
+        call = lambda sk: ops.igemm(xt, wk, bias, geom=geom, tile=TILES["256x320"], split_k=sk, **kw)   # noqa: E731
+    else:
+        B, T, HW, Cc = 2, 5, 1153, 1024                        # K = 3072 = 48 K tiles, 16 per tap
+        x = torch.randn(B, Cc, T, HW, 1, generator=g).half()
+        w = (torch.randn(320, Cc, 3, 1, 1, generator=g) * 0.03).half()
+        xt = x[..., 0].permute(0, 2, 3, 1).reshape(B * T * HW, Cc).contiguous().to(DEV)
+        wk = pack_conv3d_t3(w).to(DEV)
+        M = B * T * HW
+        bias, kw, apply = _epilogue("r1", M, 320)
+        if mode.endswith("halo"):
+            ext = torch.zeros((B * T + 2) * HW, Cc, dtype=torch.float16, device=DEV)
+            ext[HW:-HW] = xt
+            xr = x.float().permute(1, 0, 2, 3, 4).reshape(1, Cc, B * T, HW, 1).to(DEV)
+            ref = F.conv3d(xr, w.float().to(DEV), None, padding=(1, 0, 0))[0, :, :, :, 0].permute(1, 2, 0).reshape(-1, 320)
+            call = lambda sk: ops.igemm(ext[HW:], wk, bias, geom=ops.convt3_geom(0, HW), M=M, tile=TILES["256x320"], split_k=sk, **kw)   # noqa: E731
+        else:
+            ref = F.conv3d(x.float().to(DEV), w.float().to(DEV), None, padding=(1, 0, 0))[..., 0].permute(0, 2, 3, 1).reshape(-1, 320)
+            call = lambda sk: ops.igemm(xt, wk, bias, geom=ops.convt3_geom(T, HW), tile=TILES["256x320"], split_k=sk, **kw)   # noqa: E731
+    whole, split = call(False), call(True)
+    _close(whole, apply(ref), what=f"{mode} whole tiles")
+    _close(split, apply(ref), what=f"{mode} split-K")
+    assert not torch.equal(whole, split)                     # the split path ran
+    assert torch.equal(split, call(True))
+
+
 @pytest.mark.parametrize("tile", list(TILES))
 def test_repeat_launches_bit_identical_every_tile(ops, tile):
     """a race in the staged K loop (LDS-DMA landing under a fragment read) or a dropped epilogue term shows up as a
