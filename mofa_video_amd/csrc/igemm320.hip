@@ -21,8 +21,8 @@
 //     20 MFMAs of the partner wave; 6 do not).  64-byte rows: the 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3)
 //     (applied to the DMA source address and to the fragment read; tools/lds_bank_sim.py: conflict-free).
 //   * bias (and the row vector when the wave's 64 rows share one row of it: every tile that does not straddle a frame) is
-//     the INITIAL VALUE of the accumulators, loaded straight into them at tile start -- no bias handling in any epilogue,
-//     no scratch image of it (the 2 KB scratch is one 32 x 32 fp16 / 16 x 32 fp32 transpose).
+//     the INITIAL VALUE of the accumulators -- no bias handling in any epilogue.  The bias arrives through LDS one tile
+//     ahead (LDS-DMA into a 768-byte slot per wave and tile parity), the uniform row-vector row by global loads.
 //   * epilogues: no residual, uniform row vector -> activation in the fragment layout, fp16, 32 x 32 transposes, 16-byte
 //     stores; residuals / per-row row vector -> 16 x 32 fp32 transposes (half the lanes write at a time), the sum rounded once.
 // Kinds: plain (+ SiLU / ReLU / GELU), row vector, one or two residuals, GEGLU pair (value / gate rows interleaved by 16).
@@ -44,7 +44,8 @@ template <int NJ> struct Geo {
     static constexpr int TBN = WN3 * NJ * 32;
     static constexpr int PLANE = (TBM3 + TBN) * RBH;           // 36 KB / 32 KB
     static constexpr int SLOT = 2 * PLANE;                     // one K tile
-    static constexpr int LDS_BYTES = 2 * SLOT;                 // 147456 / 131072 (the epilogue transposes through a free ring plane)
+    static constexpr int BIAS0 = 2 * SLOT;                     // per wave 2 x 768 B: the bias of this tile and of the next one
+    static constexpr int LDS_BYTES = BIAS0 + 8 * 2 * 768;     // 159744 (the epilogue transposes through a free ring plane)
     static constexpr int LOOKAHEAD = 4 + NJ;                   // DMA instructions of the last two phases may be in flight
 };
 
@@ -209,12 +210,34 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         wa = XPL + (wn * NJ3 * 32 + l31) * RBH + sl;
     }
 
+    // The wave's 160 bias values travel through LDS one tile AHEAD: three 4-byte-per-lane LDS-DMA instructions issued at the
+    // start of tile t bring tile t + 1's bias (columns beyond N read as zero through the descriptor's bounds check; no bias: an
+    // empty descriptor, zeros arrive), landed long before tile t + 1 starts (every phase's counted wait covers them), so the
+    // accumulator initialisation is 20 LDS reads with no VMEM operation queued behind the previous epilogue's stores.  (The
+    // first version loaded the bias straight from global memory at tile start; tools/bias_probe.py shows no measurable
+    // difference between the two, nor between bias and no bias -- its first reading, "bias costs 15 %", was the slower first
+    // measurement after fresh allocations.)
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * 4u : 0u, 0x00020000);
+    char* bias_lds = smem + Geo<NJ3>::BIAS0 + wave * 1536;
+    auto bias_prefetch = [&](int phase_, int local_, int slot) __attribute__((always_inline)) {
+        if (phase_ != 0) return;                                   // (a split-K item starts from zero; past the end: nothing)
+        int tile_, kb_, ke_;
+        item_decode(phase_, local_, tile_, kb_, ke_);
+        const int tm_ = fdiv(tile_, aux.tiles_n), tn_ = tile_ - tm_ * tilesN;
+        const unsigned n0 = (unsigned)(tn_ * TBN3 + wn * NJ3 * 32 + lane_now());
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)(bias_lds + slot * 768 + k * 256), 4,
+                                                     (n0 + 64u * k) * 4u, 0, 0, 0);
+    };
+
     Cursor3 ca, cb;                                                // plane 0 stream, plane 1 stream
     ca.local = cb.local = walk.local;
     ca.phase = cb.phase = walk.local < walk.count ? 0 : 1;     // (no whole tile: the workgroup was kept for its split-K item)
     cur_setup(ca, 0);
     cur_setup(cb, 1);
-    // prologue: K tile 0 complete, plane 0 of K tile 1
+    // prologue: the first tile's bias, K tile 0 complete, plane 0 of K tile 1
+    bias_prefetch(walk.local < walk.count ? 0 : 1, walk.local, 0);
     issue(ca, 0, 0); advance(ca, 0);
     issue(cb, 1, 0); advance(cb, 1);
     issue(ca, 0, SLOT); advance(ca, 0);
@@ -503,10 +526,15 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
     };
 
     int gt = 0;                                                    // K tiles consumed so far (ring slot = gt & 1)
-    int cph = walk.local < walk.count ? 0 : 1, cl = walk.local;
-    for (; cph < 2; next_pos(cph, cl)) {
+    int cph = walk.local < walk.count ? 0 : 1, cl = walk.local, bslot = 0;
+    for (; cph < 2; next_pos(cph, cl), bslot ^= 1) {
         int tile, kb, ke;
         item_decode(cph, cl, tile, kb, ke);
+        {                                                          // the NEXT tile's bias into the other slot
+            int nph = cph, nl = cl;
+            next_pos(nph, nl);
+            bias_prefetch(nph, nl, bslot ^ 1);
+        }
         const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
         const int mw = tm * TBM3 + wm * MI3 * 32;                  // first output row / column of this wave
         const int nw = tn * TBN3 + wn * NJ3 * 32;
@@ -521,7 +549,7 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
             }
             idx_u = __builtin_amdgcn_readfirstlane(idx_u);
         }
-        // accumulators start at bias (+ the wave's row of the row vector): loaded straight into them
+        // accumulators start at bias (from its LDS slot) + the wave's row of the row vector
         if (SPLIT && cph == 1) {
 #pragma unroll
             for (int i = 0; i < MI3; ++i)
@@ -536,11 +564,12 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
             for (int j = 0; j < NJ3; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    int n = nw + 32 * j + 8 * g + 4 * lh_e;
-                    n = n + 4 <= a.N ? n : 0;                       // columns beyond N are never stored
-                    f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                    if (a.bias) b = *(const f32x4*)(a.bias + n);
-                    if (RV && idx_u >= 0) b += *(const f32x4*)(a.rowvec + (size_t)idx_u * a.N + n);
+                    f32x4 b = *(const f32x4*)(bias_lds + bslot * 768 + (32 * j + 8 * g + 4 * lh_e) * 4);
+                    if (RV && idx_u >= 0) {
+                        int n = nw + 32 * j + 8 * g + 4 * lh_e;
+                        n = n + 4 <= a.N ? n : 0;                   // columns beyond N are never stored
+                        b += *(const f32x4*)(a.rowvec + (size_t)idx_u * a.N + n);
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { acc[0][j][4 * g + e] = b[e]; acc[1][j][4 * g + e] = b[e]; }
                 }
