@@ -111,11 +111,16 @@ _igemm_ws_lock = threading.Lock()         # threads that share a stream (the vir
 
 
 def igemm_workspace(device):
-    """the split-K scratch of the CURRENT stream on ``device`` (one per stream: launches of different streams overlap)"""
+    """the split-K scratch of the CURRENT stream on ``device`` (one per stream: launches of different streams overlap).  At most
+    8 are kept (torch hands out side streams from a pool of 32): a buffer was allocated while its stream was current and is
+    only ever used on it, so dropping it is stream-ordered by the caching allocator like any other temporary."""
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    ws = _igemm_ws.get(key)
+    ws = _igemm_ws.pop(key, None)
     if ws is None:
-        ws = _igemm_ws[key] = torch.empty(IGEMM_WS_BYTES, dtype=torch.uint8, device=device)
+        ws = torch.empty(IGEMM_WS_BYTES, dtype=torch.uint8, device=device)
+        while len(_igemm_ws) >= 8:
+            _igemm_ws.pop(next(iter(_igemm_ws)))
+    _igemm_ws[key] = ws                                       # (re-inserted last: least recently used first)
     return ws
 
 
