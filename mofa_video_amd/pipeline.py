@@ -192,8 +192,8 @@ class FlowControlNetPipeline:
 
     def _decode(self, latents_out, T, decode_chunk_size, output_type, sh, stream_chunks=None):
         """decode_latents + tensor2vid (pipeline.py:513-518).  With several ranks the independent VAE chunks (:204-213) are
-        dealt round-robin: the result is then the list of (first_frame, frames) chunks this rank decoded.  stream_chunks: {chunk
-        index: raw fp32 [n,3,H,W]} already decoded on a side stream (Keypoint loop)."""
+        dealt round-robin (or as ``sh.owner`` says): the result is then the list of (first_frame, frames) chunks this rank
+        decoded.  stream_chunks: {chunk index: raw fp32 [n,3,H,W]} already decoded on a side stream (Keypoint loop)."""
         if output_type == "latent":
             return latents_out
         if sh.world == 1:
@@ -210,10 +210,12 @@ class FlowControlNetPipeline:
             return frames if output_type == "raw" else tensor2vid(frames, None, output_type=output_type)
         frames = []
         sf = 1.0 / self.vae.config.scaling_factor
+        owner = getattr(sh, "owner", None)                  # Keypoint loop: chunks decoded early belong to a stated rank
         for ci, s0 in enumerate(range(0, T, decode_chunk_size)):
-            if ci % sh.world == sh.rank:
+            if (owner[ci] if owner else ci % sh.world) == sh.rank:
                 z = latents_out[0, s0:s0 + decode_chunk_size]
-                fr = self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)           # fp32 [n,3,H,W]
+                fr = stream_chunks[ci] if (stream_chunks and ci in stream_chunks) else \
+                    self.vae.decode(z, num_frames=z.shape[0], _prescale=sf)            # fp32 [n,3,H,W]
                 if output_type != "raw":
                     fr = tensor2vid(fr.permute(1, 0, 2, 3).unsqueeze(0), None, output_type=output_type)[0]
                 frames.append((s0, fr))
@@ -380,6 +382,16 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
 # window, overlap average (MOFA-Video-Keypoint/pipeline/svdxt_pipeline_ctrlnet_loop.py:289-294 signature,
 # :426-429 views, :445-511 loop)
 # =========================================================================================================
+def _deal_ready_chunks(ready, world, busy_next, idle_cap=3, busy_cap=2):
+    """Which rank decodes the VAE chunks that became final before the last round(s) of the last denoise step: a rank with no
+    window in the next round takes up to ``idle_cap`` of them (a chunk decode is about a third of a window step), a rank that
+    is stepping a window up to ``busy_cap`` on its second stream (a window finalises 1.5 chunks per round at stride 12 and
+    chunks of 8); the rest wait for the next round.  Pure function of its arguments: every rank computes the same table."""
+    idle = [r for r in range(world) if r not in busy_next]
+    slots = [r for k in range(idle_cap) for r in idle] + [r for k in range(busy_cap) for r in busy_next]
+    return list(zip(ready, slots))
+
+
 def window_views(num_frames, window_size, stride):
     window_num = (num_frames - window_size) // stride + 1
     views = [(1 + i * stride, i * stride + window_size) for i in range(window_num)]
@@ -392,8 +404,10 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
       window runs the landmark adapter AND the trajectory adapter and blends their residuals by the mask, exactly as
       ``HybridFlowControlNetPipeline`` does per clip (Hybrid/pipeline/pipeline.py:479-489);
     * the VAE decode overlaps the last denoise step: in that step the windows finish in order, so every decode chunk whose
-      frames are final is decoded on a second HIP stream while the remaining windows are still being stepped; with several
-      ranks (``parallel.WindowParallel``) the chunks are dealt round-robin over the ranks instead."""
+      frames are final is decoded on a second HIP stream while the remaining windows are still being stepped.  With several
+      ranks the same holds per round (``parallel.WindowParallel``: a round = one window per rank; ranks without a window in
+      the next round take the finished chunks first) or per window (``parallel.FrameParallel``: every window on all ranks),
+      and the chunks not decoded early are dealt evenly after the loop."""
 
     def __init__(self, vae=None, image_encoder=None, unet=None, controlnet=None, scheduler=None, feature_extractor=None,
                  parallel=None, round_latents_to_fp16=False, drag_controlnet=None, overlap_decode=True):
@@ -476,14 +490,12 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         dflow = drag_flow.to(dev, torch.float32) if hybrid else None
         views = window_views(N, Tw, stride)
         from .parallel import FrameParallel
-        if isinstance(self.parallel, FrameParallel):
+        framepar = self.parallel if isinstance(self.parallel, FrameParallel) else None
+        if framepar is not None and len(set(views)) == 1 and N == Tw:
             # ONE window that is the whole clip (N == window_size: every view is frames 1 .. N-1 behind frame 0): the loop
             # degenerates to the plain denoise loop -- value = k * stepped window, count = k -- so the clip is frame-sharded
-            # exactly like FlowControlNetPipeline / HybridFlowControlNetPipeline (2-way CFG x frame shards).  Several
-            # windows cannot be frame-sharded (they overlap in time): those take parallel.WindowParallel.
-            if len(set(views)) != 1 or N != Tw:
-                raise ValueError(f"frame sharding (parallel.FrameParallel) needs a single window (num_frames == window_size); "
-                                 f"{len(set(views))} distinct windows of {Tw} over {N} frames: use parallel.WindowParallel")
+            # exactly like FlowControlNetPipeline / HybridFlowControlNetPipeline (2-way CFG x frame shards) and the latents
+            # stay sharded between the steps.
             lat = self._single_window_sharded(lat, il, emb, cond, flow, dflow, landmarks, mask, timesteps, h, w, height, width,
                                               min_guidance_scale, max_guidance_scale, controlnet_cond_scale, ctrl_scale_traj,
                                               callback_on_step_end)
@@ -492,51 +504,78 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
             if not return_dict:
                 return frames, controlnet_flow
             return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
+        # Several windows, three ways to spread them (self.parallel):
+        #   None            every window on this GPU, one after the other;
+        #   WindowParallel  the distinct windows of a step dealt to the ranks, one all-gather per round;
+        #   FrameParallel   (Layout of window_size frames) every window on ALL ranks, 2-way CFG x frame shards inside the
+        #                   window, the stepped window gathered before the overlap average -- the layout for more ranks than
+        #                   windows (on 8 ranks and 7 windows WindowParallel's single round is the faster of the two).
+        # In all three every rank holds all N latent frames and applies the same overlap average in view order.
+        sh_w = _Shard(framepar, Tw)
+        f0, f1, Tl, Bl, half, fpar = sh_w.f0, sh_w.f1, sh_w.Tl, sh_w.Bl, sh_w.half, sh_w.fpar
         # adapter state per DISTINCT window is timestep-invariant: computed once per clip (the reference recomputes it
         # every step; its last view often repeats the previous one -- SURVEY 3.5 -- and is computed once here)
         conds, dconds = {}, {}
+        fr = dict(frames=(f0, f1)) if framepar is not None else {}
         for (t0, t1) in views:
             if (t0, t1) not in conds:
                 lm = torch.cat([landmarks[:, 0:1], landmarks[:, t0:t1]], dim=1)
-                conds[(t0, t1)] = cn.prepare_condition(cond[:1], flow[:1, t0 - 1:t1 - 1], lm)
+                conds[(t0, t1)] = cn.prepare_condition(cond[:1], flow[:1, t0 - 1:t1 - 1], lm, **fr)
                 if hybrid:
-                    dconds[(t0, t1)] = drag.prepare_condition(cond[:1], dflow[:1, t0 - 1:t1 - 1])
+                    dconds[(t0, t1)] = drag.prepare_condition(cond[:1], dflow[:1, t0 - 1:t1 - 1], **fr)
         masks = _resized_masks(mask, height, width, h, w, dev) if hybrid else None
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
-        ctxs = {v: (Ctx(2, Tw), Ctx(2, Tw), Ctx(2, Tw)) for v in conds}
+        ctxs = {v: (Ctx(Bl, Tl), Ctx(Bl, Tl), Ctx(Bl, Tl)) for v in conds}
         distinct = list(conds)                                                     # distinct windows, in view order
-        wpar = self.parallel                                                       # parallel.WindowParallel or None
-        world, rank = (wpar.world, wpar.rank) if wpar is not None else (1, 0)
-        x_in = torch.zeros((2 * Tw * h * w, unet.in_ld), dtype=torch.float16, device=dev)
+        wpar = self.parallel if framepar is None else None                         # parallel.WindowParallel or None
+        if framepar is not None:
+            world, rank = sh_w.world, sh_w.rank
+        else:
+            world, rank = (wpar.world, wpar.rank) if wpar is not None else (1, 0)
+        rows = Tl * h * w
+        x_in = torch.zeros((2 * rows, unet.in_ld), dtype=torch.float16, device=dev)
+        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
+        g0, g1 = min_guidance_scale, max_guidance_scale
+        if framepar is not None:                                                   # guidance of this rank's frames of a window
+            gspan = (max_guidance_scale - min_guidance_scale) / max(Tw - 1, 1)
+            g0, g1 = min_guidance_scale + gspan * f0, min_guidance_scale + gspan * (f1 - 1)
         value = torch.empty_like(lat)
         # the views that cover each frame, and the last of them in processing order: a frame is final once that one is merged
         last_view_of = [max(idx for idx, (t0, t1) in enumerate(views) if (0 if idx == 0 else t0) <= f < t1) for f in range(N)]
-        side = torch.cuda.Stream(device=dev) if (self.overlap_decode and output_type != "latent" and world == 1) else None
-        stream_chunks = {}
+        nchunks = -(-N // decode_chunk_size)
+        rounds = wpar.rounds(distinct) if wpar is not None else [[k] for k in distinct]
+        # the decode of finished frames overlaps the rest of the LAST step on a second HIP stream wherever that step has more
+        # than one round; a chunk belongs to ``owner[ci]`` (the same table on every rank)
+        side = torch.cuda.Stream(device=dev) if (self.overlap_decode and output_type != "latent" and len(rounds) > 1) else None
+        stream_chunks, owner = {}, {}
         self._num_timesteps = len(timesteps)
         for i, t in enumerate(timesteps):
             sigma, sigma_next = sch.sigma_pair(i)
-            last_step = i == len(timesteps) - 1
+            overlap = i == len(timesteps) - 1 and side is not None
             count = [0] * N
             touched = [False] * N
-            overlap = last_step and side is not None and wpar is None
             # every window of a step reads the latents of the PREVIOUS step; when frames are finalised while later windows
             # of the (last) step still run, those windows read a snapshot
             lat_in = lat.clone() if overlap else lat
 
             def step_window(t0, t1):
-                lw = torch.cat([lat_in[0:1], lat_in[t0:t1]], dim=0).contiguous()      # frame 0 + window frames
+                lw = torch.cat([lat_in[0:1], lat_in[t0:t1]], dim=0)                   # frame 0 + window frames
+                lw = lw[f0:f1].contiguous()                                           # (this rank's frames of the window)
                 ops.prepare_model_input(lw, il, x_in, sigma)
                 c_cn, c_dr, c_un = ctxs[(t0, t1)]
-                cn.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_cn)
-                down, mid = cn.forward_tokens(x_in, c_cn, h, w, conds[(t0, t1)], controlnet_cond_scale)
+                cn.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_cn, half=half, par=fpar)
+                down, mid = cn.forward_tokens(x_loc, c_cn, h, w, conds[(t0, t1)], controlnet_cond_scale)
                 if hybrid:
-                    drag.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_dr)
-                    dd, md = drag.forward_tokens(x_in, c_dr, h, w, dconds[(t0, t1)], ctrl_scale_traj)
-                    down, mid = _blend_residuals(down, mid, dd, md, masks, 2 * Tw)
-                unet.make_ctx(float(t), emb, added_time_ids, 2, Tw, base=c_un)
-                noise = unet.forward_tokens(x_in, c_un, h, w, down, mid)
-                ops.cfg_euler_step_(lw, noise, sigma, sigma_next, min_guidance_scale, max_guidance_scale)
+                    drag.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_dr, half=half, par=fpar)
+                    dd, md = drag.forward_tokens(x_loc, c_dr, h, w, dconds[(t0, t1)], ctrl_scale_traj)
+                    down, mid = _blend_residuals(down, mid, dd, md, masks, Bl * Tl)
+                unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+                noise = unet.forward_tokens(x_loc, c_un, h, w, down, mid)
+                if Bl == 1:
+                    noise = framepar.gather_cfg(noise)
+                ops.cfg_euler_step_(lw, noise, sigma, sigma_next, g0, g1)
+                if fpar is not None:
+                    lw = fpar.gather_frames(lw.reshape(Tl, 4 * h * w), 1).reshape(Tw, 4, h, w)
                 return lw
 
             def merge(idx, lw):
@@ -560,53 +599,63 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
                         lat[f].zero_()
 
             done = {}
-            if wpar is None:
-                frontier = 0                                                          # frames [0, frontier) are final (last step)
-                for idx, (t0, t1) in enumerate(views):
-                    if (t0, t1) not in done:
-                        done[(t0, t1)] = step_window(t0, t1)
-                    merge(idx, done[(t0, t1)])
-                    if overlap and idx < len(views) - 1:
-                        # every frame whose last covering view is merged can be averaged now; whole decode chunks below the
-                        # frontier go to the second stream while the next windows run
-                        newf = frontier
-                        while newf < N and last_view_of[newf] <= idx:
-                            newf += 1
-                        if newf > frontier:
-                            finalize(range(frontier, newf))
-                            lat_r = self._round(lat)
-                            ready = torch.cuda.Event()
-                            ready.record()
-                            for ci, s0 in enumerate(range(0, N, decode_chunk_size)):
-                                s1 = min(s0 + decode_chunk_size, N)
-                                if ci not in stream_chunks and s1 <= newf:
-                                    with torch.cuda.stream(side):
-                                        side.wait_event(ready)
-                                        lat_r.record_stream(side)         # (lat_r may be a temporary of the main stream: keep
-                                        z = lat_r[s0:s1]                  #  its block out of the allocator until the decode ran)
-                                        stream_chunks[ci] = self.vae.decode(z, num_frames=s1 - s0,
-                                                                            _prescale=1.0 / self.vae.config.scaling_factor)
-                            frontier = newf
-                finalize(range(frontier, N))
-            else:                                         # window-parallel: one window per rank and round
-                for rnd in wpar.rounds(distinct):
+            merged, frontier = 0, 0                               # views [0, merged) are merged, frames [0, frontier) final
+            for ri, rnd in enumerate(rounds):
+                if wpar is None:
+                    done[rnd[0]] = step_window(*rnd[0])
+                else:                                             # window-parallel: one window per rank and round
                     mine = rnd[rank]
                     lw = step_window(*mine) if mine is not None else torch.zeros((Tw,) + tuple(lat.shape[1:]),
                                                                                 dtype=lat.dtype, device=dev)
                     for key, got in zip(rnd, wpar.gather(lw)):
                         if key is not None:
                             done[key] = got
-                for idx, (t0, t1) in enumerate(views):
-                    merge(idx, done[(t0, t1)])
-                finalize(range(N))
+                if not overlap or ri == len(rounds) - 1:
+                    continue
+                # views are merged in view order as soon as their window is stepped (the same summation order as after the
+                # loop); every frame whose last covering view is merged can be averaged now, and whole decode chunks below
+                # the frontier go to the second stream while the next round runs
+                while merged < len(views) and views[merged] in done:
+                    merge(merged, done[views[merged]])
+                    merged += 1
+                newf = frontier
+                while newf < N and last_view_of[newf] < merged:
+                    newf += 1
+                finalize(range(frontier, newf))
+                frontier = newf
+                ready = [ci for ci in range(nchunks) if ci not in owner and min((ci + 1) * decode_chunk_size, N) <= frontier]
+                busy_next = [r for r in range(world) if wpar is None or rounds[ri + 1][r] is not None]
+                for ci, r in _deal_ready_chunks(ready, world, busy_next):
+                    owner[ci] = r
+                mine = [ci for ci in ready if owner.get(ci) == rank]
+                if mine:
+                    lat_r = self._round(lat)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    with torch.cuda.stream(side):
+                        side.wait_event(ev)
+                        lat_r.record_stream(side)                 # (lat_r may be a temporary of the main stream: keep its
+                        for ci in mine:                           #  block out of the allocator until the decode ran)
+                            s0 = ci * decode_chunk_size
+                            z = lat_r[s0:min(s0 + decode_chunk_size, N)]
+                            stream_chunks[ci] = self.vae.decode(z, num_frames=z.shape[0],
+                                                                _prescale=1.0 / self.vae.config.scaling_factor)
+            while merged < len(views):
+                merge(merged, done[views[merged]])
+                merged += 1
+            finalize(range(frontier, N))
             lat = self._round(lat)
             lat = self._callback(callback_on_step_end, i, t, lat, (1, N, 4, h, w))
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
             if callback_on_step_end is not None:
-                stream_chunks = {}                        # a callback may have replaced the latents after the last step
+                stream_chunks, owner = {}, {}             # a callback may have replaced the latents after the last step
+        rest = [ci for ci in range(nchunks) if ci not in owner]   # the chunks still to decode: dealt evenly
+        for j, ci in enumerate(rest):
+            owner[ci] = j % world
         sh = _Shard(None, N)
         sh.world, sh.rank = world, rank
+        sh.owner = owner
         frames = self._decode(lat.reshape(1, N, 4, h, w), N, decode_chunk_size, output_type, sh, stream_chunks)
         if not return_dict:
             return frames, controlnet_flow

@@ -198,7 +198,7 @@ def test_keypoint_loop_window_parallel_equals_single_rank(models, world):
 def test_keypoint_single_window_frame_sharded_equals_single_rank(models, world, hybrid):
     """BASELINE config 3 is ONE window that is the whole clip (num_frames == window_size): with a parallel.FrameParallel the
     Keypoint pipeline frame-shards it (2-way CFG x frame shards) like the Traj / Hybrid pipelines -- it must reproduce the
-    single-rank window loop (whose two identical views average to the stepped window); several windows are refused."""
+    single-rank window loop (whose two identical views average to the stepped window)."""
     import threading
 
     from mofa_video_amd.parallel import FrameParallel, Layout, ThreadComm, ThreadWorld
@@ -243,6 +243,6 @@ def test_keypoint_single_window_frame_sharded_equals_single_rank(models, world, 
         e = rel_l2(o, ref)
         print(f"keypoint single window (hybrid={hybrid}) world {world} rank {r}: latents rel-L2 vs single rank {e:.3e}")
         assert tuple(o.shape) == tuple(ref.shape) and e < 2e-3, (r, e)
-    # several windows cannot be frame-sharded
+    # a Layout built for another window size is refused (several windows: tests/test_pipeline_api_gpu.py)
     with pytest.raises(ValueError):
         run(FrameParallel(Layout(1, 0, T), ThreadComm(ThreadWorld(1), 0)), frames=T, window=T - 1)

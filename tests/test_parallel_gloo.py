@@ -155,3 +155,11 @@ def test_frames_only_layout_gloo(T):
 @pytest.mark.parametrize("world,nwin", [(2, 3), (2, 4), (4, 3)])
 def test_window_parallel_gloo(world, nwin):
     mp.spawn(_window_worker, args=(world, _free_port(), nwin), nprocs=world, join=True)
+
+
+def test_deal_ready_chunks_prefers_idle_ranks():
+    """the common table that says which rank decodes a VAE chunk that became final before the last round of the last step"""
+    from mofa_video_amd.pipeline import _deal_ready_chunks
+    assert _deal_ready_chunks([0, 1, 2, 3, 4, 5], 4, busy_next=[0, 1, 2]) == [(0, 3), (1, 3), (2, 3), (3, 0), (4, 1), (5, 2)]
+    assert _deal_ready_chunks([0, 1, 2], 1, busy_next=[0]) == [(0, 0), (1, 0)]      # one GPU: two per round, the rest wait
+    assert _deal_ready_chunks([], 8, busy_next=list(range(7))) == []

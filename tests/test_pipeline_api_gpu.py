@@ -197,3 +197,98 @@ def test_keypoint_overlapped_decode_is_bit_identical_and_callbacks_run(ldmk):
             None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=4, stride=4,
             height=H, width=W, num_frames=N, latents=inp["latents"], image_embeddings=inp["image_embeddings"],
             image_latents=inp["image_latents"])
+
+
+def _run_ranks(world, fn):
+    """fn(rank, thread_world) on ``world`` virtual ranks (threads of this process, one GPU)"""
+    import threading
+
+    from mofa_video_amd.parallel import ThreadWorld
+    tw = ThreadWorld(world)
+    results, errors = [None] * world, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            results[r] = fn(r, tw)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            for b in tw.barriers.values():
+                b.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(600)
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_keypoint_window_parallel_decode_overlaps_last_step(ldmk, world):
+    """Window-parallel long video with fewer ranks than windows: in the last step the frames below the merged views are
+    final after every round, their VAE chunks are decoded on a second stream during the next round (idle ranks first) and
+    the rest is dealt after the loop.  Every chunk is decoded exactly once, by the rank the common table names, and equals
+    the single-rank frames bit for bit."""
+    from mofa_video_amd.parallel import ThreadComm, WindowParallel
+    from mofa_video_amd.pipeline import KeypointFlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    of, od, ou, hf, hd, hu, hv = ldmk
+    N, win, stride, chunk = 10, 4, 2, 2                                  # 4 distinct windows, 5 decode chunks
+    inp, lm, drag, mask = _long_inputs(N)
+
+    def run(parallel=None, overlap=True):
+        pipe = KeypointFlowControlNetPipeline(vae=hv, unet=hu, controlnet=hf, scheduler=EulerDiscreteScheduler(), parallel=parallel,
+                                              overlap_decode=overlap)
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=win,
+                    stride=stride, height=H, width=W, num_frames=N, num_inference_steps=2, decode_chunk_size=chunk,
+                    latents=inp["latents"], output_type="raw", image_embeddings=inp["image_embeddings"],
+                    image_latents=inp["image_latents"]).frames
+    ref = run()                                                          # [1, 3, N, H, W]
+    for overlap in (True, False):
+        res = _run_ranks(world, lambda r, tw: run(WindowParallel(ThreadComm(tw, r), r, world), overlap))
+        seen = {}
+        for r, chunks in enumerate(res):
+            for s0, fr in chunks:
+                assert s0 not in seen, (s0, r, seen)
+                seen[s0] = r
+                assert torch.equal(fr, ref[0, :, s0:s0 + fr.shape[0]].permute(1, 0, 2, 3)), (overlap, r, s0)
+        assert sorted(seen) == list(range(0, N, chunk)), seen
+        print(f"window-parallel world {world} overlap {overlap}: chunk first frame -> rank {seen}")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_keypoint_several_windows_frame_sharded(ldmk, world):
+    """Several windows under parallel.FrameParallel (Layout of window_size frames): every window runs on all ranks, 2-way CFG x
+    frame shards, and is gathered before the overlap average; latents as on one rank (GroupNorm summation order differs)
+    and every decode chunk comes back from exactly one rank."""
+    from mofa_video_amd.parallel import FrameParallel, Layout, ThreadComm
+    from mofa_video_amd.pipeline import KeypointFlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    of, od, ou, hf, hd, hu, hv = ldmk
+    N, win, stride, chunk = 8, 4, 2, 2
+    inp, lm, drag, mask = _long_inputs(N)
+
+    def run(parallel=None, output_type="latent"):
+        pipe = KeypointFlowControlNetPipeline(vae=hv, unet=hu, controlnet=hf, drag_controlnet=hd, scheduler=EulerDiscreteScheduler(),
+                                              parallel=parallel)
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=win,
+                    stride=stride, height=H, width=W, num_frames=N, num_inference_steps=2, decode_chunk_size=chunk,
+                    latents=inp["latents"], output_type=output_type, image_embeddings=inp["image_embeddings"],
+                    image_latents=inp["image_latents"], drag_flow=drag, mask=mask, ctrl_scale_traj=0.8).frames
+    ref = run()
+    res = _run_ranks(world, lambda r, tw: run(FrameParallel(Layout(world, r, win), ThreadComm(tw, r))))
+    for r, o in enumerate(res):
+        e = rel_l2(o, ref)
+        print(f"keypoint loop, 3 windows frame-sharded, world {world} rank {r}: latents rel-L2 vs single rank {e:.3e}")
+        assert tuple(o.shape) == tuple(ref.shape) and e < 2e-3, (r, e)
+    ref_frames = run(output_type="raw")
+    res = _run_ranks(world, lambda r, tw: run(FrameParallel(Layout(world, r, win), ThreadComm(tw, r)), "raw"))
+    seen = set()
+    for r, chunks in enumerate(res):
+        for s0, fr in chunks:
+            assert s0 not in seen
+            seen.add(s0)
+            e = rel_l2(fr, ref_frames[0, :, s0:s0 + fr.shape[0]].permute(1, 0, 2, 3))
+            assert e < 1e-2, (r, s0, e)
+    assert sorted(seen) == list(range(0, N, chunk))
