@@ -200,11 +200,31 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
         }
     }
 
+    // The wave's 64 bias values travel through its LDS scratch: one 4-byte-per-lane DMA at the START of the tile (the
+    // scratch is idle during the K loop; columns beyond N read as zero through the descriptor's bounds check), so the
+    // epilogue starts with LDS reads instead of a global-memory round trip.
+    char* scr = smem + SCRATCH0 + wave * SCRATCH_WAVE;
+    const auto rsb = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * 4u : 0u, 0x00020000);
+    auto bias_prefetch = [&](int nw, int slot = 0) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)(scr + slot * 256), 4,
+                                                 (unsigned)(nw + lane_now()) * 4u, 0, 0, 0);
+    };
+    // GEGLU kind (BIAS_INIT): the bias is the INITIAL VALUE of the accumulators, as in igemm320.hip -- its epilogue is bound by
+    // VALU issue (about 15 instructions per output; the two bias adds were 2 of them) and does not transpose through the
+    // scratch, so the scratch can hold two 256-byte bias slots: the DMA issued at the start of tile t brings tile t + 1's
+    // bias (same instruction count per tile as before: the counted waits do not change), retired by the second phase's
+    // counted wait of tile t; the first tile's bias is the oldest operation of the prologue.
+    constexpr bool BIAS_INIT = GEGLU;
+
     Cursor ca, cb;                                                 // (X0, W0, W1) stream, X1 stream
     ca.local = cb.local = walk.local;
     cur_setup(ca, 0, true);
     cur_setup(cb, 1, false);
-    // prologue: K tile 0 complete, (X0, W) of K tile 1: 6 + 2 + 6 DMA instructions
+    // prologue: (BIAS_INIT: the first tile's bias,) K tile 0 complete, (X0, W) of K tile 1: 6 + 2 + 6 DMA instructions
+    if constexpr (BIAS_INIT) {
+        const int tile0 = walk.start + walk.local;
+        bias_prefetch((tile0 - fdiv(tile0, aux.tiles_n) * tilesN) * TBN + wn * NJ * 32, 0);
+    }
     issue_x(ca, 0, 0); issue_w(ca, 0); advance(ca, 0, true);
     issue_x(cb, 1, 0); advance(cb, 1, false);
     issue_x(ca, 0, STB); issue_w(ca, STB); advance(ca, 0, true);
@@ -279,15 +299,6 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
     };
 
     // ---- epilogue pieces -------------------------------------------------------------------------------------------------
-    // The wave's 64 bias values travel through its LDS scratch: one 4-byte-per-lane DMA at the START of the tile (the
-    // scratch is idle during the K loop; columns beyond N read as zero through the descriptor's bounds check), so the
-    // epilogue starts with LDS reads instead of a global-memory round trip.
-    char* scr = smem + SCRATCH0 + wave * SCRATCH_WAVE;
-    const auto rsb = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? (unsigned)a.N * 4u : 0u, 0x00020000);
-    auto bias_prefetch = [&](int nw) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsb, (__attribute__((address_space(3))) void*)scr, 4,
-                                                 (unsigned)(nw + lane_now()) * 4u, 0, 0, 0);
-    };
     auto act_apply = [&](auto ac, float v) __attribute__((always_inline)) -> float {
         constexpr int ACT = decltype(ac)::v;
         if constexpr (ACT == MOFA_ACT_SILU) return silu_f(v);
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
         float saccv = a.s_acc;                                     // VGPR operand on purpose (see igemm.hip's epilogue)
         asm volatile("" : "+v"(saccv));
         f32x4 bv[NJ][4];                                           // bias (from the scratch); UNI: bias + row vector
-        if (!RV || UNI) {
+        if (!BIAS_INIT && (!RV || UNI)) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -377,8 +388,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float val = acc[i][g >> 1][4 * (g & 1) + e] + bv[g >> 1][g & 1][e];
-                        const float gate = acc[i][g >> 1][8 + 4 * (g & 1) + e] + bv[g >> 1][2 + (g & 1)][e];
+                        const float val = acc[i][g >> 1][4 * (g & 1) + e];          // (BIAS_INIT: the bias is already in)
+                        const float gate = acc[i][g >> 1][8 + 4 * (g & 1) + e];
                         if constexpr (SACC1) o[g][e] = (f16)(val * (gate * gelu_phi_f(gate)));
                         else o[g][e] = (f16)(saccv * val * gelu_erf_f(saccv * gate));
                     }
@@ -506,18 +517,41 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
     };
 
     int gt = 0;                                                    // K tiles consumed so far (ring slot = gt & 1)
-    for (int cl = walk.local; cl < walk.count; cl += walk.stride) {
+    int bslot = 0;                                                 // (BIAS_INIT) scratch slot holding this tile's bias
+    for (int cl = walk.local; cl < walk.count; cl += walk.stride, bslot ^= 1) {
         const int tile = walk.start + cl;
         const int tm = fdiv(tile, aux.tiles_n), tn = tile - tm * tilesN;
         if (VAR & 64) { stamp(9); tr[12] += nk; }          // tile set-up since the last stamp
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
+        if constexpr (BIAS_INIT) {
+            // the NEXT tile's bias into the other slot (no next tile: this tile's once more, never read -- the instruction
+            // count per tile stays static), then the accumulators start at this tile's bias
+            int tn2 = tn;
+            if (cl + walk.stride < walk.count) {
+                const int tile2 = walk.start + cl + walk.stride;
+                tn2 = tile2 - fdiv(tile2, aux.tiles_n) * tilesN;
+            }
+            bias_prefetch(tn2 * TBN + wn * NJ * 32, bslot ^ 1);
+            const int lh_e = lane_now() >> 5;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 b = *(const f32x4*)(scr + bslot * 256 + (32 * j + 8 * g + 4 * lh_e) * 4);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][4 * g + e] = b[e];
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-        bias_prefetch(tn * TBN + wn * NJ * 32);                    // (no bias: an empty descriptor, zeros arrive)
+            bias_prefetch(tn * TBN + wn * NJ * 32);                // (no bias: an empty descriptor, zeros arrive)
+        }
         if (!(VAR & 1) && grp == 1) __builtin_amdgcn_s_barrier();  // second wave group runs one barrier behind
         for (int kt = 0; kt < nk; ++kt, ++gt) {
             const int bo = (gt & 1) * STB, bn = STB - bo;          // ring slot of this K tile / of the next one

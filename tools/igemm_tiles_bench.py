@@ -91,10 +91,17 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--quick", action="store_true", help="first 10 shapes only")
     ap.add_argument("--tiles", default="192,256p,320p,auto")
+    ap.add_argument("--only", default="", help="comma-separated substrings of the shape tags to run")
+    ap.add_argument("--lib", default="", help="A/B: load this build of libmofa_hip.so instead of the in-tree one")
     args = ap.parse_args()
+    if args.lib:
+        lib.LIB_PATH = os.path.abspath(args.lib)
+        print("library:", lib.LIB_PATH)
     lib.load()
     tiles = [t for t in TILES if t[0] in args.tiles.split(",")]
     shapes = SHAPES[:10] if args.quick else SHAPES
+    if args.only:
+        shapes = [sh for sh in shapes if any(o in sh[6] for o in args.only.split(","))]
     print(f"{'shape':30s} {'M':>8s} {'N':>6s} {'K':>6s} {'epi':>6s} " + " ".join(f"{n:>7s}" for n, _ in tiles) + "   best")
     tot = {n: 0.0 for n, _ in tiles}
     tot_best, tot_fl = 0.0, 0.0
