@@ -317,6 +317,8 @@ def main():
                     help="N > 1: 'shard' = ONE clip per step partitioned over the ranks (2-way CFG x N/2 frame shards, "
                          "RCCL exchanges at the temporal ops; strong scaling) or 'replicas' = one independent clip per "
                          "rank (no data-path collective; weak scaling)")
+    ap.add_argument("--lib", default="", help="A/B switch: load this build of libmofa_hip.so instead of the in-tree one "
+                    "(same-box comparison of two kernel builds; the path is echoed in config.library)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -339,6 +341,8 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from mofa_video_amd import lib, ops
+    if args.lib:
+        lib.LIB_PATH = os.path.abspath(args.lib)
     lib.load()                                              # fails loudly without the HIP library
     cfg = args.config
     pipe = build_config_pipeline(dev, cfg, seed=0)
@@ -461,7 +465,7 @@ def main():
                        "num_frames": nfr, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
                        "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
-                       "output_finite": finite, "comm_paths": comm_paths,
+                       "output_finite": finite, "comm_paths": comm_paths, **({"library": args.lib} if args.lib else {}),
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},
             "roofline": roofline,
         }

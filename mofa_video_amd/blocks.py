@@ -144,10 +144,15 @@ class GegluFF:
         if M * hid * 2 <= self.CHUNK_ABOVE_BYTES or rows <= 0 or rows >= M:
             h = ops.igemm(x, self.w1, self.b1, act=L.ACT_GEGLU_PAIR)
             return self.out(h, **epilogue)
+        # fixed-size chunks (65 536 rows = 256 row tiles = one full round of the persistent grid on the bench's level 0); a short
+        # remainder joins the last chunk instead of running as launches of its own -- on the bench 2 048 rows (one frame, 9 216
+        # rows, behind a frame-periodic row vector): 8 / 36 tiles on 256 CUs at 60-470 TF/s, 27 ms per clip
+        bounds = list(range(0, M, rows)) + [M]
+        if len(bounds) > 2 and bounds[-1] - bounds[-2] < rows // 4:
+            del bounds[-2]
         out = torch.empty((M, self.out.n_real), dtype=torch.float16, device=x.device)
-        h = torch.empty((rows, hid), dtype=torch.float16, device=x.device)
-        for m0 in range(0, M, rows):
-            m1 = min(m0 + rows, M)
+        h = torch.empty((max(b - a for a, b in zip(bounds, bounds[1:])), hid), dtype=torch.float16, device=x.device)
+        for m0, m1 in zip(bounds, bounds[1:]):
             hh = ops.igemm(x[m0:m1], self.w1, self.b1, act=L.ACT_GEGLU_PAIR, out=h[:m1 - m0])
             kw = {k: (v[m0:m1] if k in ("r1", "r2") and v is not None else v) for k, v in epilogue.items()}
             if rowvec is not None:

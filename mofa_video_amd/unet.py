@@ -103,6 +103,11 @@ class UNetSpatioTemporalConditionControlNetModel:
     def forward_tokens(self, x, c, H, W, down_res, mid_res):
         """x: fp16 [B*T*H*W, in_ld] (channels >= in_channels zero); down_res: 12 token tensors; mid_res: token
         tensor.  Returns fp16 [B*T*H*W, 4] noise prediction (token-major)."""
+        return self.decode_tokens(self.encode_tokens(x, c, H, W), c, down_res, mid_res)
+
+    def encode_tokens(self, x, c, H, W):
+        """conv_in + down blocks + mid block: the part of the forward that does not depend on the adapter's residuals (the
+        ControlNet trunk of the same step is independent of it)"""
         sample = self.conv_in(x, H, W)
         skips = [sample]
         counts = []
@@ -111,6 +116,10 @@ class UNetSpatioTemporalConditionControlNetModel:
             skips += [o[0] for o in outs]
             counts.append(len(skips))
         sample = self.mid_block(sample, c, H, W)
+        return sample, skips, counts, H, W
+
+    def decode_tokens(self, enc, c, down_res, mid_res):
+        sample, skips, counts, H, W = enc
         ops.axpby_(mid_res, sample, 1.0, 1.0)
         # residual quirk, applied after the mid block has consumed the last (un-added) skip
         mult = residual_multiplicity(counts, len(down_res))

@@ -26,11 +26,16 @@ def run_case(M, C, chunks):
     res = {}
     for rows in chunks:
         rows_ = M if rows == 0 else rows
-        h = torch.empty(min(rows_, M), 4 * C, dtype=torch.float16, device=DEV)
+
+        merge = rows < 0                       # negative: fixed chunks of -rows, a remainder < 1/4 chunk joins the last one
+        rows_ = -rows if merge else rows_
+        bounds = list(range(0, M, rows_)) + [M]
+        if merge and len(bounds) > 2 and bounds[-1] - bounds[-2] < rows_ // 4:
+            del bounds[-2]
+        h = torch.empty(max(b - a for a, b in zip(bounds, bounds[1:])), 4 * C, dtype=torch.float16, device=DEV)
 
         def ff():
-            for m0 in range(0, M, rows_):
-                m1 = min(m0 + rows_, M)
+            for m0, m1 in zip(bounds, bounds[1:]):
                 hh = ops.igemm(x[m0:m1], w1, b1, act=lib.ACT_GEGLU_PAIR, out=h[:m1 - m0])
                 ops.igemm(hh, w2, b2, r1=r1[m0:m1], s1=1.0, out=out[m0:m1])
         for _ in range(2):
@@ -47,10 +52,13 @@ def run_case(M, C, chunks):
             ts.append(e0.elapsed_time(e1) / 4)
         res[rows] = sorted(ts)[1]
         chk = out.float().abs().mean().item()
-        print(f"M {M} C {C}  chunk rows {rows_:7d}: {res[rows] * 1e3:8.1f} us per feed-forward   (hidden chunk {min(rows_, M) * 4 * C * 2 / 1e6:6.0f} MB; |out| {chk:.4f})")
+        print(f"M {M} C {C}  chunk rows {rows_:7d}{' (remainder merged)' if merge else '':19s}: {res[rows] * 1e3:8.1f} us per feed-forward   (hidden chunk {h.shape[0] * 4 * C * 2 / 1e6:6.0f} MB; |out| {chk:.4f})")
     return res
 
 
 if __name__ == "__main__":
-    run_case(460800, 320, [0, 230400, 131072, 65536, 57600, 32768])
-    run_case(115200, 640, [0, 57600, 38400, 28800])
+    if len(sys.argv) > 1 and sys.argv[1] == "merge":
+        run_case(460800, 320, [65536, -65536, 65536, -65536])
+    else:
+        run_case(460800, 320, [0, 230400, 131072, 65536, 57600, 32768])
+        run_case(115200, 640, [0, 57600, 38400, 28800])

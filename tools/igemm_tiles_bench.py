@@ -28,6 +28,7 @@ SHAPES = [
     ("gemm", 460800, 320, 1280, "r1", 21, "L0 ff out"),
     ("conv", (50, 72, 128), 320, 320, "rv", 11, "L0 conv3x3 320"),
     ("gemm", 460800, 320, 320, "r1", 31, "L0 proj / attn out"),
+    ("gemm", 460800, 320, 320, "none", 0, "L0 proj_in (no residual; weight in the row above)"),
     ("gemm", 115200, 640, 2560, "r1", 21, "L1 ff out"),
     ("gemm", 28800, 1280, 5120, "r1", 21, "L2 ff out"),
     ("conv", (50, 36, 64), 640, 640, "rv", 9, "L1 conv3x3 640"),
