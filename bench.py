@@ -317,6 +317,9 @@ def main():
                     help="N > 1: 'shard' = ONE clip per step partitioned over the ranks (2-way CFG x N/2 frame shards, "
                          "RCCL exchanges at the temporal ops; strong scaling) or 'replicas' = one independent clip per "
                          "rank (no data-path collective; weak scaling)")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="every clip in single-stream order (pipeline.overlap_adapter = False): the mode the roofline leg and the "
+                         "rocprofv3 kernel statistics are taken in -- kernel durations are exclusive only when nothing runs beside")
     ap.add_argument("--lib", default="", help="A/B switch: load this build of libmofa_hip.so instead of the in-tree one "
                     "(same-box comparison of two kernel builds; the path is echoed in config.library)")
     args = ap.parse_args()
@@ -377,18 +380,30 @@ def main():
     for _ in range(args.warmup):
         run_config(pipe, inp, cfg)
     # Roofline leg: HIP events around every implicit-GEMM / attention / softsplat launch of the LAST clip of the timed region
-    # (on the launch stream).  Bracketing all K clips was measured to cost 2.3 % of the clip time (two event records per launch
-    # x 13 000 timed launches per clip: 6 674 against 6 525 ms, profiles/r03c_bench_{timer,notimer}.log), which `value` would
-    # carry; one instrumented clip keeps the live measurement and bounds its cost to 2.3 % / K.
+    # (on the launch stream), and that clip runs in SINGLE-STREAM order.  Two reasons, both measured:
+    #  * bracketing all K clips costs 2.3 % of the clip time (two event records per launch x 19 000 timed launches per clip:
+    #    6 674 against 6 525 ms, profiles/r03c_bench_{timer,notimer}.log), which `value` would carry;
+    #  * the pipeline enqueues the adapter's ControlNet trunk and the UNet's encoder half on two HIP streams (pipeline.py,
+    #    _denoise_forward: 3.0-4.4 % of a step).  A launch's event (or rocprofv3) duration then includes the time it waits for
+    #    the CUs the other stream's kernel holds, so it no longer measures the kernel: the per-launch durations are taken with
+    #    nothing running beside (the same mode as profiles/r03*_kernel_stats_bench.md, `--single-stream`).
+    # `value` is still all K clips / the whole timed region, the instrumented one included; config.clip_ms has both kinds.
     timer = ops.LaunchTimer()
+    pipe.overlap_adapter = not args.single_stream
+    clip_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
     t0 = time.perf_counter()
+    clip_ev[0].record()
     for i in range(args.steps):
-        ops.TIMER = timer if (i == args.steps - 1 and not args.no_launch_timer) else None
+        if i == args.steps - 1 and not args.no_launch_timer:
+            ops.TIMER, pipe.overlap_adapter = timer, False
         frames = run_config(pipe, inp, cfg)
+        clip_ev[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
+    pipe.overlap_adapter = not args.single_stream
+    clip_ms = [round(clip_ev[i].elapsed_time(clip_ev[i + 1]), 1) for i in range(args.steps)]
     # "pt" output = the reference's tensor2vid result: a list with one [T,3,H,W] tensor in [0,1] per batch element
     # (single rank), or the list of (first_frame, [n,3,H,W]) VAE chunks this rank decoded (shard mode)
     finite = all(bool(torch.isfinite(f[1] if isinstance(f, tuple) else f).all().item()) for f in frames)
@@ -418,14 +433,15 @@ def main():
                 pass
         roofline = dict(kernel="igemm_f16_kernel", bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
-                        launches_per_clip=ig["launches"], timed_with_events="the last of the K timed clips",
+                        launches_per_clip=ig["launches"],
+                        timed_with_events="the last of the K timed clips, run in single-stream order (exclusive kernel durations)",
                         avg_launch_us=round(avg_s * 1e6, 1),
                         algorithmic_tflop_per_launch=round(ig["flops"] / max(ig["launches"], 1) / 1e12, 5),
-                        share_of_clip_time=round(ig["seconds"] / (dt / args.steps), 3))
+                        share_of_clip_time=round(ig["seconds"] / (clip_ms[-1] * 1e-3), 3))
         if at:
             roofline["attn_spatial_kernel"] = dict(achieved=round(at["flops"] / at["seconds"] / 1e12, 1), unit="TFLOP/s",
                                                    frac=round(at["flops"] / at["seconds"] / 1e12 / MFMA_PEAK_TFLOPS, 4),
-                                                   share_of_clip_time=round(at["seconds"] / (dt / args.steps), 3))
+                                                   share_of_clip_time=round(at["seconds"] / (clip_ms[-1] * 1e-3), 3))
         # HBM-bound kernels of the adapter on REAL bytes (8 TB/s peak; MI355X_MICROARCH.md): the forward-splat warp
         # (count / scan / fill / sort / gather, timed as one op; bytes = per flow frame and target pixel: C fp16 read + C fp16
         # written + the flow + its CSR entries) and the full-resolution 16 / 32-channel condition-embedding convolutions (rows x
@@ -465,6 +481,9 @@ def main():
                        "num_frames": nfr, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
                        "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
+                       "streams": ("single stream" if (args.single_stream or (mode == "shard" and cfg != 5)) else
+                                   "adapter trunk || UNet encoder on two HIP streams; the last timed clip (HIP events) single-stream"),
+                       "clip_ms": clip_ms,
                        "output_finite": finite, "comm_paths": comm_paths, **({"library": args.lib} if args.lib else {}),
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},
             "roofline": roofline,

@@ -15,6 +15,13 @@ entirely in libmofa_hip.so on token-major fp16 activations:
         mofa_cfg_euler_step         (CFG with per-frame guidance + v-prediction Euler step, fp32 latents)
     decode: temporal VAE decoder, chunks of ``decode_chunk_size`` frames.
 
+Within a step the adapter's ControlNet trunk(s) and the UNet's encoder half (conv_in, down blocks, mid block) do not depend
+on each other (the residuals are added after the mid block): without frame sharding the trunks are enqueued on a second HIP
+stream and the encoder on the caller's (``_denoise_forward``; ``overlap_adapter=False`` restores the single-stream order).  Every
+launch is a grid of persistent one-per-CU workgroups, so the second stream's kernel takes exactly the CUs the first one's tail
+round leaves idle, and one stream's launch gap is covered by the other's kernel: 3.0-4.4 % of a denoise step on one MI355X
+(tools/two_stream_probe.py), bit-identical results (same kernels, same tiles, same order per stream).
+
 Image conditioning (once per clip before the loop, pipeline.py:330-352) also runs on the library when the
 pipeline holds an ``image_encoder`` (mofa_video_amd.clip) and a VAE with encoder weights: ``image`` is then the PIL image /
 [1,3,H,W] tensor in [0, 1] of the reference call (mofa_video_amd/frontend.py).  Precomputed conditioning can be passed
@@ -78,6 +85,8 @@ class FlowControlNetPipeline:
         self.device = unet.device
         self.parallel = parallel
         self.round_latents_to_fp16 = round_latents_to_fp16
+        self.overlap_adapter = True          # adapter trunk(s) || UNet encoder on two HIP streams (see _denoise_forward)
+        self._adapter_stream = None
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, unet=None, controlnet=None, device="cuda", variant=None,
@@ -106,6 +115,43 @@ class FlowControlNetPipeline:
         if controlnet is not None:
             kw["controlnet"] = controlnet
         return cls(vae=vae, image_encoder=enc, unet=unet, scheduler=sch, **kw)
+
+    # ---- one network evaluation of a denoise step ---------------------------------------------------------------------------
+    def _denoise_forward(self, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, adapters, c_un, masks=None):
+        """``adapters``: [(controlnet, its Ctx, its per-clip condition, conditioning scale)], one entry, or two (face, drag)
+        whose residuals are blended by ``masks`` (Hybrid/pipeline/pipeline.py:479-489) -> the UNet's noise prediction (tokens).
+        Without frame sharding the trunks run on ``self._adapter_stream`` while the UNet's encoder half runs on the caller's
+        stream; the streams join before the residuals are added (unet.decode_tokens).  Frame-sharded ranks keep one stream:
+        their exchanges (halo, GroupNorm sums, token gather) are ordered by the host's issue order on the transport's stream."""
+        unet = self.unet
+
+        def trunks():
+            res = []
+            for net, ctx, cond, scale in adapters:
+                net.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=ctx, half=half, par=fpar)
+                res.append(net.forward_tokens(x_loc, ctx, h, w, cond, scale))
+            down, mid = res[0]
+            if len(res) == 2:
+                down, mid = _blend_residuals(down, mid, res[1][0], res[1][1], masks, Bl * Tl)
+            return down, mid
+
+        if fpar is not None or not self.overlap_adapter:
+            down, mid = trunks()
+            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+            return unet.forward_tokens(x_loc, c_un, h, w, down, mid)
+        cur = torch.cuda.current_stream(self.device)
+        if self._adapter_stream is None:
+            self._adapter_stream = torch.cuda.Stream(device=self.device)
+        side = self._adapter_stream
+        side.wait_stream(cur)                                   # the model input (and everything before it) is ready
+        with torch.cuda.stream(side):
+            down, mid = trunks()
+        unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+        enc = unet.encode_tokens(x_loc, c_un, h, w)
+        cur.wait_stream(side)
+        for r in list(down) + [mid]:                            # allocated on the side stream, consumed (and freed) on this one
+            r.record_stream(cur)
+        return unet.decode_tokens(enc, c_un, down, mid)
 
     # ---- pieces of the reference __call__ ---------------------------------------------------------------------------------
     def check_inputs(self, image, height, width):                      # pipeline.py:222-234
@@ -269,10 +315,8 @@ class FlowControlNetPipeline:
         for i, t in enumerate(timesteps):                                 # :447-511
             sigma, sigma_next = sch.sigma_pair(i)
             ops.prepare_model_input(lat, il, x_in, sigma)
-            cn.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_cn, half=half, par=fpar)
-            down_res, mid_res = cn.forward_tokens(x_loc, c_cn, h, w, warped, controlnet_cond_scale)
-            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
-            noise = unet.forward_tokens(x_loc, c_un, h, w, down_res, mid_res)
+            noise = self._denoise_forward(x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w,
+                                          [(cn, c_cn, warped, controlnet_cond_scale)], c_un)
             if Bl == 1:
                 noise = sh.par.gather_cfg(noise)                          # both halves of this frame shard
             ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
@@ -357,13 +401,8 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
         for i, t in enumerate(timesteps):
             sigma, sigma_next = sch.sigma_pair(i)
             ops.prepare_model_input(lat, il, x_in, sigma)
-            face.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_f, half=half, par=fpar)
-            df, mf = face.forward_tokens(x_loc, c_f, h, w, cf, ctrl_scale_ldmk)
-            drag.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_d, half=half, par=fpar)
-            dd, md = drag.forward_tokens(x_loc, c_d, h, w, cd, ctrl_scale_traj)
-            down, mid = _blend_residuals(df, mf, dd, md, masks, Bl * Tl)
-            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_u, half=half, par=fpar)
-            noise = unet.forward_tokens(x_loc, c_u, h, w, down, mid)
+            noise = self._denoise_forward(x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w,
+                                          [(face, c_f, cf, ctrl_scale_ldmk), (drag, c_d, cd, ctrl_scale_traj)], c_u, masks)
             if Bl == 1:
                 noise = sh.par.gather_cfg(noise)
             ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
@@ -440,14 +479,8 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         for i, t in enumerate(timesteps):
             sigma, sigma_next = sch.sigma_pair(i)
             ops.prepare_model_input(lat, il, x_in, sigma)
-            cn.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_f, half=half, par=fpar)
-            down, mid = cn.forward_tokens(x_loc, c_f, h, w, cf, cn_scale)
-            if hybrid:
-                drag.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_d, half=half, par=fpar)
-                dd, md = drag.forward_tokens(x_loc, c_d, h, w, cd, traj_scale)
-                down, mid = _blend_residuals(down, mid, dd, md, masks, Bl * Tl)
-            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_u, half=half, par=fpar)
-            noise = unet.forward_tokens(x_loc, c_u, h, w, down, mid)
+            adapters = [(cn, c_f, cf, cn_scale)] + ([(drag, c_d, cd, traj_scale)] if hybrid else [])
+            noise = self._denoise_forward(x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, adapters, c_u, masks)
             if Bl == 1:
                 noise = sh.par.gather_cfg(noise)
             ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
@@ -563,14 +596,10 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
                 lw = lw[f0:f1].contiguous()                                           # (this rank's frames of the window)
                 ops.prepare_model_input(lw, il, x_in, sigma)
                 c_cn, c_dr, c_un = ctxs[(t0, t1)]
-                cn.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_cn, half=half, par=fpar)
-                down, mid = cn.forward_tokens(x_loc, c_cn, h, w, conds[(t0, t1)], controlnet_cond_scale)
+                adapters = [(cn, c_cn, conds[(t0, t1)], controlnet_cond_scale)]
                 if hybrid:
-                    drag.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_dr, half=half, par=fpar)
-                    dd, md = drag.forward_tokens(x_loc, c_dr, h, w, dconds[(t0, t1)], ctrl_scale_traj)
-                    down, mid = _blend_residuals(down, mid, dd, md, masks, Bl * Tl)
-                unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
-                noise = unet.forward_tokens(x_loc, c_un, h, w, down, mid)
+                    adapters.append((drag, c_dr, dconds[(t0, t1)], ctrl_scale_traj))
+                noise = self._denoise_forward(x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, adapters, c_un, masks)
                 if Bl == 1:
                     noise = framepar.gather_cfg(noise)
                 ops.cfg_euler_step_(lw, noise, sigma, sigma_next, g0, g1)

@@ -45,6 +45,20 @@ def test_fullsize_repeat_runs_bit_identical(full):
     assert torch.equal(a, b)
 
 
+def test_fullsize_two_streams_equal_single_stream(full):
+    """the adapter trunk beside the UNet encoder on two HIP streams (the default) against the single-stream order, at full
+    occupancy: same bits"""
+    pipe, inp, run = full
+    assert pipe.overlap_adapter
+    a = run()
+    pipe.overlap_adapter = False
+    try:
+        b = run()
+    finally:
+        pipe.overlap_adapter = True
+    assert torch.equal(a, b)
+
+
 def test_fullsize_zero_adapter_scale_ignores_flow(full):
     pipe, inp, run = full
     a = run(scale=0.0)

@@ -82,6 +82,14 @@ def test_hybrid_pipeline(models):
     e = rel_l2(out, ref)
     print(f"hybrid latents after 2 steps: rel-L2 {e:.3e}")
     assert e < 2e-2, e
+    # both adapters' trunks on the second HIP stream beside the UNet encoder (the default) == the single-stream order, bit for bit
+    assert pipe.overlap_adapter
+    pipe.overlap_adapter = False
+    out1 = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV),
+                drag_flow=drag_flow, mask=mask, height=H, width=W, num_frames=T, num_inference_steps=2,
+                latents=inp["latents"], output_type="latent", ctrl_scale_traj=0.8, ctrl_scale_ldmk=1.1,
+                image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames
+    assert torch.equal(out, out1)
 
 
 def test_keypoint_window_loop(models):
@@ -103,6 +111,11 @@ def test_keypoint_window_loop(models):
     e = rel_l2(out, ref)
     print(f"keypoint loop latents after 2 steps: rel-L2 {e:.3e}")
     assert e < 2e-2, e
+    pipe.overlap_adapter = False                                     # single-stream order: the same bits
+    out1 = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=win,
+                stride=stride, height=H, width=W, num_frames=N, num_inference_steps=2, latents=inp["latents"],
+                output_type="latent", image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames
+    assert torch.equal(out, out1)
 
 
 @pytest.mark.parametrize("world", [2, 4])

@@ -115,6 +115,22 @@ def test_denoise_loop_and_decode(models, inputs):
     e = rel_l2(out.frames, ref_lat)
     print(f"latents after {steps} steps: rel-L2 {e:.3e}")
     assert e < 2e-2, e
+    # the default runs the adapter's trunk on a second HIP stream beside the UNet encoder: same bits as the single-stream order,
+    # also when repeated (a stream-ordering or allocator-reuse race would show up as run-to-run differences)
+    assert pipe.overlap_adapter
+    pipe.overlap_adapter = False
+    serial = pipe(None, controlnet_condition=inputs["cond"], controlnet_flow=inputs["flow"], height=H, width=W,
+                  num_frames=T, num_inference_steps=steps, decode_chunk_size=3, latents=inputs["latents"],
+                  output_type="latent", image_embeddings=inputs["image_embeddings"],
+                  image_latents=inputs["image_latents"]).frames
+    assert torch.equal(out.frames, serial)
+    pipe.overlap_adapter = True
+    for _ in range(3):
+        again = pipe(None, controlnet_condition=inputs["cond"], controlnet_flow=inputs["flow"], height=H, width=W,
+                     num_frames=T, num_inference_steps=steps, decode_chunk_size=3, latents=inputs["latents"],
+                     output_type="latent", image_embeddings=inputs["image_embeddings"],
+                     image_latents=inputs["image_latents"]).frames
+        assert torch.equal(again, serial)
     # decode the ORACLE latents with the HIP VAE (isolates the decoder) and the HIP latents end to end
     from mofa_video_amd.vae import decode_latents
     fr = decode_latents(hv, ref_lat.to(DEV), T, 3)
