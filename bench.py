@@ -377,6 +377,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pipe.overlap_adapter = not args.single_stream
     for _ in range(args.warmup):
         run_config(pipe, inp, cfg)
     # Roofline leg: HIP events around every implicit-GEMM / attention / softsplat launch of the LAST clip of the timed region

@@ -16,6 +16,7 @@ def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     dev = torch.device("cuda", 0)
     pipe = bench.build_pipeline(dev)
+    pipe.overlap_adapter = False          # single-stream order: per-kernel counters / durations with nothing running beside
     inp = bench.synthetic_inputs(dev)
     out = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=bench.H, width=bench.W,
                num_frames=bench.T, num_inference_steps=steps, decode_chunk_size=8, latents=inp["latents"],
