@@ -320,6 +320,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="every clip in single-stream order (pipeline.overlap_adapter = False): the mode the roofline leg and the "
                          "rocprofv3 kernel statistics are taken in -- kernel durations are exclusive only when nothing runs beside")
+    ap.add_argument("--split-decoder", type=int, default=-1, help="A/B switch: pipeline.split_decoder = 0 | 1 (default: the pipeline's)")
     ap.add_argument("--lib", default="", help="A/B switch: load this build of libmofa_hip.so instead of the in-tree one "
                     "(same-box comparison of two kernel builds; the path is echoed in config.library)")
     args = ap.parse_args()
@@ -378,6 +379,8 @@ def main():
         torch.cuda.synchronize()
 
     pipe.overlap_adapter = not args.single_stream
+    if args.split_decoder >= 0:
+        pipe.split_decoder = bool(args.split_decoder)
     for _ in range(args.warmup):
         run_config(pipe, inp, cfg)
     # Roofline leg: HIP events around every implicit-GEMM / attention / softsplat launch of the LAST clip of the timed region
@@ -483,7 +486,8 @@ def main():
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
                        "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
                        "streams": ("single stream" if (args.single_stream or (mode == "shard" and cfg != 5)) else
-                                   "adapter trunk || UNet encoder on two HIP streams; the last timed clip (HIP events) single-stream"),
+                                   "adapter trunk || UNet encoder, then the decoder's two CFG halves, on two HIP streams; the last timed clip (HIP "
+                                   "events) single-stream"),
                        "clip_ms": clip_ms,
                        "output_finite": finite, "comm_paths": comm_paths, **({"library": args.lib} if args.lib else {}),
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},

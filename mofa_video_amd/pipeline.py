@@ -86,6 +86,7 @@ class FlowControlNetPipeline:
         self.parallel = parallel
         self.round_latents_to_fp16 = round_latents_to_fp16
         self.overlap_adapter = True          # adapter trunk(s) || UNet encoder on two HIP streams (see _denoise_forward)
+        self.split_decoder = True            # ... and the UNet decoder's two CFG halves on the same two streams
         self._adapter_stream = None
 
     @classmethod
@@ -151,7 +152,30 @@ class FlowControlNetPipeline:
         cur.wait_stream(side)
         for r in list(down) + [mid]:                            # allocated on the side stream, consumed (and freed) on this one
             r.record_stream(cur)
-        return unet.decode_tokens(enc, c_un, down, mid)
+        if not (self.split_decoder and Bl == 2 and half is None):
+            return unet.decode_tokens(enc, c_un, down, mid)
+        # The UNet's decoder half has nothing to run beside, so its two CFG halves go down the two streams (rows [0, rows) and
+        # [rows, 2 rows) of every token tensor; the per-half contexts are the ones a rank of the 2-way CFG layout uses): one
+        # half's GroupNorm / attention / epilogue phases overlap the other's MFMA phases.  Half-size launches choose their
+        # tiles for themselves, so this order is deterministic but not bit-identical to the single-stream one.
+        if not hasattr(c_un, "halves"):
+            c_un.halves = [Ctx(1, Tl), Ctx(1, Tl)]
+        sample, skips, counts, Hm, Wm = enc
+        outs = [None, None]
+        side.wait_stream(cur)                                   # the encoder's outputs are ready
+        for hf, st in enumerate((cur, side)):
+            with torch.cuda.stream(st):
+                ch = c_un.halves[hf]
+                unet.make_ctx(float(t), emb, added_time_ids, 1, Tl, base=ch, half=hf, par=None)
+
+                def rows_of(tt, hf=hf):
+                    n = tt.shape[0] // 2
+                    return tt[hf * n:(hf + 1) * n]
+                outs[hf] = unet.decode_tokens((rows_of(sample), [rows_of(k) for k in skips], counts, Hm, Wm), ch,
+                                              [rows_of(r) for r in down], rows_of(mid))
+        cur.wait_stream(side)
+        outs[1].record_stream(cur)
+        return torch.cat(outs, 0)
 
     # ---- pieces of the reference __call__ ---------------------------------------------------------------------------------
     def check_inputs(self, image, height, width):                      # pipeline.py:222-234

@@ -82,8 +82,16 @@ def test_hybrid_pipeline(models):
     e = rel_l2(out, ref)
     print(f"hybrid latents after 2 steps: rel-L2 {e:.3e}")
     assert e < 2e-2, e
-    # both adapters' trunks on the second HIP stream beside the UNet encoder (the default) == the single-stream order, bit for bit
-    assert pipe.overlap_adapter
+    # both adapters' trunks on the second HIP stream beside the UNet encoder == the single-stream order, bit for bit; with the
+    # decoder's CFG halves on the two streams as well (the default) half-size launches pick their own tiles: rounding noise
+    assert pipe.overlap_adapter and pipe.split_decoder
+    pipe.split_decoder = False
+    out_ts = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV),
+                  drag_flow=drag_flow, mask=mask, height=H, width=W, num_frames=T, num_inference_steps=2,
+                  latents=inp["latents"], output_type="latent", ctrl_scale_traj=0.8, ctrl_scale_ldmk=1.1,
+                  image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames
+    assert rel_l2(out, out_ts) < 2e-3
+    out = out_ts
     pipe.overlap_adapter = False
     out1 = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV),
                 drag_flow=drag_flow, mask=mask, height=H, width=W, num_frames=T, num_inference_steps=2,
@@ -111,7 +119,11 @@ def test_keypoint_window_loop(models):
     e = rel_l2(out, ref)
     print(f"keypoint loop latents after 2 steps: rel-L2 {e:.3e}")
     assert e < 2e-2, e
-    pipe.overlap_adapter = False                                     # single-stream order: the same bits
+    pipe.split_decoder = False
+    out = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=win,
+               stride=stride, height=H, width=W, num_frames=N, num_inference_steps=2, latents=inp["latents"],
+               output_type="latent", image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames
+    pipe.overlap_adapter = False                                     # single-stream order: the same bits as trunk || encoder
     out1 = pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=win,
                 stride=stride, height=H, width=W, num_frames=N, num_inference_steps=2, latents=inp["latents"],
                 output_type="latent", image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames

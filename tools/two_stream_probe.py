@@ -81,7 +81,33 @@ def main():
             main_s.wait_stream(s_)
         return torch.cat(outs, 0)
 
-    modes = {"one stream": lambda: step(False), "CN || encoder": lambda: step(True),
+    cd = [Ctx(1, T), Ctx(1, T)]
+
+    def step_mixed():
+        """ControlNet || UNet encoder on the full CFG batch, then the UNet decoder as two half-batch streams"""
+        cn.make_ctx(1.5, emb, ids, 2, T, base=c_cn)
+        unet.make_ctx(1.5, emb, ids, 2, T, base=c_un)
+        side.wait_stream(main_s)
+        with torch.cuda.stream(side):
+            down, mid = cn.forward_tokens(x, c_cn, h, w, warped, 1.0)
+        sample, skips, counts, H2, W2 = unet.encode_tokens(x, c_un, h, w)
+        main_s.wait_stream(side)
+        for t in list(down) + [mid]:
+            t.record_stream(main_s)
+        outs = [None, None]
+        st = [main_s, side]
+        side.wait_stream(main_s)
+        for hf in range(2):
+            with torch.cuda.stream(st[hf]):
+                unet.make_ctx(1.5, emb, ids, 1, T, base=cd[hf], half=hf)
+                half_rows = lambda t_: t_[hf * (t_.shape[0] // 2):(hf + 1) * (t_.shape[0] // 2)]
+                enc_h = (half_rows(sample), [half_rows(k) for k in skips], counts, H2, W2)
+                outs[hf] = unet.decode_tokens(enc_h, cd[hf], [half_rows(r) for r in down], half_rows(mid))
+        main_s.wait_stream(side)
+        outs[1].record_stream(main_s)
+        return torch.cat(outs, 0)
+
+    modes = {"one stream": lambda: step(False), "CN || encoder": lambda: step(True), "CN||enc, dec0||dec1": step_mixed,
              "half || half": lambda: step_halves(False), "4 streams": lambda: step_halves(True)}
     ref = step(False).clone()
     torch.cuda.synchronize()
