@@ -127,11 +127,14 @@ class GegluFF:
         self.w1, self.b1 = s.dev(pack_linear(w)), s.dev(f32(b))
         self.out = Linear(s.sub("net.2"))
 
-    # rows per pass when the 4C-wide hidden tensor of the whole batch would not fit the 256 MB Infinity Cache: the projection
-    # and net.2 then run chunk by chunk (<= 160 MB of hidden rows each, whole 256-row tiles) so that net.2 reads its operand from
-    # the cache instead of HBM.  Same kernels on the same tiles: bit-identical.  Level 0 of the bench (460 800 x 1280 = 1.18 GB):
-    # 1 556 -> 1 465 us per feed-forward (tools/ff_chunk_probe.py); no gain at level 1 (590 MB), so only above 768 MB.
-    CHUNK_ABOVE_BYTES = 768 << 20
+    # Row-chunked form: projection and net.2 chunk by chunk (<= CHUNK_BYTES of hidden rows each, whole 256-row tiles) so that net.2
+    # reads its operand from the 256 MB Infinity Cache instead of HBM when the 4C-wide hidden tensor of the whole batch does not
+    # fit (level 0 of the bench: 460 800 x 1280 = 1.18 GB).  Same kernels on the same tiles.  OFF by default: in isolation the
+    # level-0 feed-forward gains 6 % (1 556 -> 1 465 us, tools/ff_chunk_probe.py), in the clip it loses 0.3-0.4 % in every mode
+    # (single stream 6 430 / 6 452 -> 6 409 / 6 427 ms, two streams 6 296 / 6 308 -> 6 278 / 6 285: profiles/r03c_ff_chunking_ab.log)
+    # -- 6 300 more launches per clip, and beside other kernels the cache is not the feed-forward's alone.  Kept (and tested)
+    # for footprints where the hidden tensor must not exist as a whole; set CHUNK_ABOVE_BYTES to enable.
+    CHUNK_ABOVE_BYTES = 1 << 62
     CHUNK_BYTES = 160 << 20
 
     def __call__(self, x, **epilogue):
