@@ -548,7 +548,10 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (kind != 7) {
             // 256x320 (igemm320.hip): 0.58 per area (10 % less LDS-DMA, 7 % fewer fragment reads per flop than 256x256); its
             // epilogues move 25 % more outputs per tile
-            static const double epi320[9] = {3.0, 10.0, 10.0, 11.5, 3.5, 10.5, 10.5, 12.0, 5.0};   // fitted: profiles/r03_igemm_tiles_bench.log
+            static const double epi320[9] = {3.0, 9.0, 10.0, 11.5, 3.5, 9.4, 10.5, 12.0, 5.0};   // fitted: profiles/r03_igemm_tiles_bench.log;
+            // [1], [5] lowered from 10.0 / 10.5 in r03c so that the K = N = 320 residual launches leave the 192x128 tile (alone a
+            // draw: 352-414 against 372-403 TF/s by box; in the clip - 0.27 %, profiles/r03c_cost_model_and_splitk_ab.log:
+            // beside a second stream the 17 % of padded columns of 3 x 128 are no longer free)
             const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 320);
             // a partial last round split along K (igemm320_split) costs 1 / S of a round + the fix-up pass
             const int S = kind == 8 ? 1 : igemm320_split(t, (int)nk, n_cu, a->workspace ? a->workspace_bytes : 0);
