@@ -485,7 +485,7 @@ def main():
                        "num_frames": nfr, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
                        "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
-                       "streams": ("single stream" if (args.single_stream or (mode == "shard" and cfg != 5)) else
+                       "streams": ("single stream" if (args.single_stream or (mode == "shard" and cfg != 5 and world > 2)) else
                                    "adapter trunk || UNet encoder, then the decoder's two CFG halves, on two HIP streams; the last timed clip (HIP "
                                    "events) single-stream"),
                        "clip_ms": clip_ms,
