@@ -58,6 +58,7 @@ class Ctx:
         self.par = None           # parallel.FrameParallel when this rank holds only frames [f0, f1) of the clip
         self.ctx16_all = None     # fp16 [B_global, cross_dim]: both CFG halves' embeddings (temporal-context quirk)
         self.half = 0             # global CFG-half index of local batch row 0
+        self.halves = None        # [Ctx(1, T), Ctx(1, T)] of a B = 2 context whose CFG halves are evaluated separately (pipeline.py)
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -158,7 +158,7 @@ class FlowControlNetPipeline:
         # [rows, 2 rows) of every token tensor; the per-half contexts are the ones a rank of the 2-way CFG layout uses): one
         # half's GroupNorm / attention / epilogue phases overlap the other's MFMA phases.  Half-size launches choose their
         # tiles for themselves, so this order is deterministic but not bit-identical to the single-stream one.
-        if not hasattr(c_un, "halves"):
+        if c_un.halves is None:
             c_un.halves = [Ctx(1, Tl), Ctx(1, Tl)]
         sample, skips, counts, Hm, Wm = enc
         outs = [None, None]
