@@ -160,7 +160,8 @@ int mofa_gn_finalize_sums(const double* sums, const float* gamma, const float* b
                           mofa_stream_t stream);
 /* fused finalize + apply (single-rank path): every workgroup combines the partial sums of its statistics set itself (fp64,
  * fixed order) and applies y = (x - mean) * rstd * gamma + beta, optional SiLU -- no scale / shift buffers, no finalize launch.
- * Meant for frames_per_stat * mofa_gn_nparts(HW, C) <= 512 entries (100 KB of partials re-read per workgroup from L2). */
+ * Meant for frames_per_stat * mofa_gn_nparts(HW, C) <= 512 entries (100 KB of partials re-read per workgroup from L2).
+ * C <= 4096 (the same limit as mofa_gn_partial_f16), C % 32 == 0. */
 int mofa_gn_apply_f16(const void* x, const float* part, const float* gamma, const float* beta, void* y,
                       int nframes, int HW, int C, int ldx, int ldy, int frames_per_stat, float eps, int silu,
                       mofa_stream_t stream);

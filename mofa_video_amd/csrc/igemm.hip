@@ -505,8 +505,8 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
-            n_cu = cus;
-        ready = true;
+            n_cu = cus >= 8 ? (cus / 8) * 8 : 8;              // persistent grids are multiples of 8 (one per XCD): every tile /
+        ready = true;                                         // round / split-K count below uses the SAME rounded figure
     }
     if (a->tile != 0 && a->tile != MOFA_TILE_128X128 && a->tile != MOFA_TILE_192X128 && a->tile != MOFA_TILE_256X256 &&
         a->tile != MOFA_TILE_256X320)

@@ -370,8 +370,8 @@ extern "C" int mofa_gn_apply_f16(const void* x, const float* part, const float* 
                                  int HW, int C, int ldx, int ldy, int frames_per_stat, float eps, int silu,
                                  mofa_stream_t stream) {
     if (!x || !part || !gamma || !beta || !y || nframes <= 0 || HW <= 0 || frames_per_stat <= 0 ||
-        nframes % frames_per_stat != 0 || C % 32 != 0 || C % 8 != 0 || C > 8192 || ldx % 8 != 0 || ldy % 8 != 0)
-        return MOFA_EINVAL;
+        nframes % frames_per_stat != 0 || C % 32 != 0 || C % 8 != 0 || C > 4096 || ldx % 8 != 0 || ldy % 8 != 0)
+        return MOFA_EINVAL;                                  // C <= 4096 as mofa_gn_partial_f16 (C * 8 B of dynamic + 8.5 KB static LDS)
     const int nparts = mofa_gn_nparts(HW, C);
     // rows per workgroup: about 64 K elements each (16 vectors of 8 per thread), at least 2 workgroups per CU in total
     int rpw = (65536 + C - 1) / C;

@@ -113,14 +113,19 @@ _igemm_ws_lock = threading.Lock()         # threads that share a stream (the vir
 def igemm_workspace(device):
     """the split-K scratch of the CURRENT stream on ``device`` (one per stream: launches of different streams overlap).  At most
     8 are kept (torch hands out side streams from a pool of 32): a buffer was allocated while its stream was current and is
-    only ever used on it, so dropping it is stream-ordered by the caching allocator like any other temporary."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
-    ws = _igemm_ws.pop(key, None)
-    if ws is None:
-        ws = torch.empty(IGEMM_WS_BYTES, dtype=torch.uint8, device=device)
-        while len(_igemm_ws) >= 8:
-            _igemm_ws.pop(next(iter(_igemm_ws)))
-    _igemm_ws[key] = ws                                       # (re-inserted last: least recently used first)
+    only ever used on it, so dropping it is stream-ordered by the caching allocator like any other temporary.  Look-up, insert
+    and eviction happen under ``_igemm_ws_lock`` (virtual-rank threads share a stream and this dict); key and launch stream
+    (``lib.stream_ptr``) are both taken from the CURRENT device, which must be ``device``."""
+    cur = torch.cuda.current_device()
+    assert device.index is None or device.index == cur, f"tensor on {device}, current device {cur}"
+    key = (cur, torch.cuda.current_stream().cuda_stream)
+    with _igemm_ws_lock:
+        ws = _igemm_ws.pop(key, None)
+        if ws is None:
+            ws = torch.empty(IGEMM_WS_BYTES, dtype=torch.uint8, device=device)
+            while len(_igemm_ws) >= 8:
+                _igemm_ws.pop(next(iter(_igemm_ws)))
+        _igemm_ws[key] = ws                                   # (re-inserted last: least recently used first)
     return ws
 
 

@@ -220,15 +220,24 @@ class FrameParallel:
         all_gather_into_tensor whose input aliases its output slot (K|V exchange) and the batched isend / irecv halo
         exchange -- and compares with what the plain list all_gather delivers.  A path that raises or returns wrong data is
         switched off ON EVERY RANK of the frame group (the verdict is all-reduced), so the run continues on the conservative
-        path (pad + all_gather + compaction, as for more than 32 key slots; all_gather-based halo).  Returns a dict for the
-        caller to report.  Meant for the first run on a new transport: bench.py calls it in shard mode."""
+        path (pad + all_gather + compaction, as for more than 32 key slots; all_gather-based halo).  Covers WRONG-DATA failures
+        and exceptions every rank of the group raises alike (an unsupported call); a rank that raises alone while its peers
+        are already inside the collective leaves them blocked -- that case ends at the process group's own
+        timeout (torch.distributed's default), not in this check.  Returns a dict for the caller to report.  Meant for the
+        first run on a new transport: bench.py calls it in shard mode."""
         lay, grp = self.lay, self.lay.frame_group
         report = {"kv_gather": "in-place all_gather_into_tensor", "halo": "batched p2p" if self.p2p else "all_gather"}
         if len(grp) == 1:
             return report
         rows, C = 8, 16
-        mine = torch.full((lay.T_loc * rows, C), float(lay.shard + 1), dtype=torch.float16, device=device)
-        ref = self.comm.all_gather(torch.full((lay.T_max * rows, C), float(lay.shard + 1), dtype=torch.float16, device=device), grp)
+
+        def pattern(shard, nrows):
+            """row r of a shard holds shard * 128 + r in every column: a slot landing at the wrong offset, a shifted slot or
+            rows permuted inside a slot all change the comparison (fp16 holds integers below 2048 exactly; r < 64)"""
+            col = torch.arange(nrows, dtype=torch.float32, device=device) + 128.0 * shard
+            return col.to(torch.float16).unsqueeze(1).repeat(1, C).contiguous()
+        mine = pattern(lay.shard, lay.T_loc * rows)
+        ref = self.comm.all_gather(pattern(lay.shard, lay.T_max * rows), grp)
         # --- K|V path
         ok = 1.0
         try:
@@ -253,12 +262,11 @@ class FrameParallel:
         if self.p2p:
             ok = 1.0
             try:
-                first = torch.full((rows, C), 10.0 + lay.shard, dtype=torch.float16, device=device)
-                last = torch.full((rows, C), 20.0 + lay.shard, dtype=torch.float16, device=device)
+                first, last = pattern(lay.shard, rows), pattern(lay.shard, rows) + 1024.0
                 fp, fn = self.comm.exchange_halo(first, last, lay.prev_rank, lay.next_rank)
-                if lay.prev_rank is not None and not bool((fp == 20.0 + lay.shard - 1).all()):
+                if lay.prev_rank is not None and not torch.equal(fp, pattern(lay.shard - 1, rows) + 1024.0):
                     ok = 0.0
-                if lay.next_rank is not None and not bool((fn == 10.0 + lay.shard + 1).all()):
+                if lay.next_rank is not None and not torch.equal(fn, pattern(lay.shard + 1, rows)):
                     ok = 0.0
             except Exception as e:  # noqa: BLE001
                 ok = 0.0
