@@ -165,6 +165,13 @@ int mofa_gn_finalize_sums(const double* sums, const float* gamma, const float* b
 int mofa_gn_apply_f16(const void* x, const float* part, const float* gamma, const float* beta, void* y,
                       int nframes, int HW, int C, int ldx, int ldy, int frames_per_stat, float eps, int silu,
                       mofa_stream_t stream);
+/* the same for a statistics set whose frames are sharded over ranks (new work; the reference is single-GPU): `part_all` = the
+ * all-gathered partials of the WHOLE set, `nentries` x [32][2] fp32 (zero entries for padding frames), combined by every
+ * workgroup in entry order; `count_per_group` = elements per group over the whole set.  Applies that one set to the `nframes`
+ * frames of x (the rank's own frames, or a halo frame received raw from a neighbour shard).  C <= 4096, nentries <= 4096. */
+int mofa_gn_apply_gathered_f16(const void* x, const float* part_all, int nentries, double count_per_group,
+                               const float* gamma, const float* beta, void* y, int nframes, int HW, int C,
+                               int ldx, int ldy, float eps, int silu, mofa_stream_t stream);
 /* y = x*scale[frame][c] + shift[frame][c]; optional SiLU */
 int mofa_affine_act_f16(const void* x, const float* scale, const float* shift, void* y,
                         int nframes, int HW, int C, int ldx, int ldy, int silu, mofa_stream_t stream);

@@ -265,21 +265,53 @@ class SpatioTemporalResBlock:
             g = self.tnorm2(g, N, HW, frames_per_stat=T, silu=True)
             # alpha*xs + (1-alpha)*(xs + conv) = xs + (1-alpha)*conv
             return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0)
-        # ---- frames of the clip sharded over ranks (one CFG half per rank): GroupNorm statistics are all-reduced,
-        #      the (3,1,1) convs read one halo frame from each neighbour shard (zeros at the clip ends) ----
+        # ---- frames of the clip sharded over ranks (one CFG half per rank; mofa_video_amd/parallel.py) ----
         assert c.B == 1
-        M = T * HW
-        gn = dict(frames_per_stat=T, silu=True, reduce_fn=par.reduce_gn, frames_total=par.T_full)
-        g = ops.group_norm(xs, self.tnorm1.g, self.tnorm1.b, N, HW, self.tnorm1.eps, **gn)
-        ext = par.halo(g, HW)
-        kw = dict(geom=ops.convt3_geom(0, HW), M=M)
-        if self.ttemb is not None:
-            g = ops.igemm(ext[HW:], self.tconv1.w, self.tconv1.b, **tvec(self.ttemb, self.ttemb_off), **kw)
+        g = _sharded_norm_convt3(self.tnorm1, self.tconv1, xs, c, HW,
+                                 **(tvec(self.ttemb, self.ttemb_off) if self.ttemb is not None else {}))
+        return _sharded_norm_convt3(self.tnorm2, self.tconv2, g, c, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0)
+
+
+def _sharded_norm_convt3(norm, conv, x, c, HW, r1=None, **epi):
+    """GroupNorm over the WHOLE clip (+ SiLU) -> (3,1,1) convolution, on the T = c.T frames of the clip this rank holds.
+    One exchange group (parallel.FrameParallel): the raw boundary frames of x leave for the neighbour shards at once; the
+    GroupNorm partials are all-gathered (the only wait of the compute stream) and every rank combines them itself; the own
+    frames are normalised straight into the halo-extended buffer the convolution reads; the interior frames are convolved
+    while the boundary frames travel, the received frames are normalised with the same statistics on arrival, and the first
+    and last frame are convolved last.  Zero frames at the clip ends = the reference convolution's zero padding."""
+    par, T = c.par, c.T
+    M, Cc = T * HW, x.shape[1]
+    nparts = ops.gn_nparts(HW, Cc)
+    buf, own = par.part_buffer(nparts, x.device)
+    ops.gn_partial_into(x, own, T, HW)
+    with par.turn("norm+conv(3,1,1)"):
+        halo = par.halo_begin(x, HW)
+        par.gather_partials(buf, nparts)
+    cnt = float(par.T_full) * HW * (Cc // 32)
+    ext = torch.empty(((T + 2) * HW, Cc), dtype=x.dtype, device=x.device)
+    ops.gn_apply_gathered(x, buf, cnt, norm.g, norm.b, norm.eps, ext[HW:(T + 1) * HW], T, HW, silu=True)
+    out = torch.empty((M, conv.w.shape[0]), dtype=x.dtype, device=x.device)
+    geom = ops.convt3_geom(0, HW)                                   # unclipped: the halo rows lie before / after a.x
+
+    def launch(f0, f1):
+        """output frames [f0, f1) of the shard"""
+        rr = r1[f0 * HW:f1 * HW] if r1 is not None else None
+        ops.igemm(ext[(f0 + 1) * HW:], conv.w, conv.b, geom=geom, M=(f1 - f0) * HW, out=out[f0 * HW:f1 * HW], r1=rr, **epi)
+    split = par.split_convs and T >= 4
+    if split:
+        launch(1, T - 1)
+    fp, fn = halo.wait()
+    for src, dst in ((fp, ext[:HW]), (fn, ext[(T + 1) * HW:])):
+        if src is None:
+            dst.zero_()
         else:
-            g = ops.igemm(ext[HW:], self.tconv1.w, self.tconv1.b, **kw)
-        g = ops.group_norm(g, self.tnorm2.g, self.tnorm2.b, N, HW, self.tnorm2.eps, **gn)
-        ext = par.halo(g, HW)
-        return ops.igemm(ext[HW:], self.tconv2.w, self.tconv2.b, s_acc=1.0 - self.alpha, r1=xs, s1=1.0, **kw)
+            ops.gn_apply_gathered(src, buf, cnt, norm.g, norm.b, norm.eps, dst, 1, HW, silu=True)
+    if split:
+        launch(0, 1)
+        launch(T - 1, T)
+    else:
+        launch(0, T)
+    return out
 
 
 class CrossAttnVec:
@@ -385,7 +417,8 @@ class TransformerSpatioTemporal:
                 # never read by the attention kernel.
                 hid, own = par.kv_buffer(HW, Cc, f.device)
                 fn = self.tnorm1(f, out=own)
-                work = par.kv_gather_begin(hid, HW)
+                with par.turn("token gather"):
+                    work = par.kv_gather_begin(hid, HW)
                 q = self.tattn1.q(fn)
                 work.wait()
                 kv = ops.igemm(hid, self.tattn1.wqkv[Cc:])
@@ -395,7 +428,8 @@ class TransformerSpatioTemporal:
                 fn = self.tnorm1(f)
                 kv, own = par.kv_buffer(HW, 2 * Cc, fn.device)
                 self.tattn1.kv_into(fn, own)
-                work = par.kv_gather_begin(kv, HW)
+                with par.turn("K|V gather"):
+                    work = par.kv_gather_begin(kv, HW)
                 q = self.tattn1.q(fn)
                 work.wait()
                 a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.kv_slots, HW, self.heads,
@@ -407,7 +441,8 @@ class TransformerSpatioTemporal:
                 kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
                 ops.copy2d(k, kv[:, :Cc])
                 ops.copy2d(v, kv[:, Cc:])
-                kv = par.gather_frames(kv, HW)
+                with par.turn("K|V gather (compacting)"):
+                    kv = par.gather_frames(kv, HW)
                 a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.T_full, HW, self.heads,
                                       head_dim=self.tattn1.head_dim, Tq=T)
         # temporal cross-attention row vector.  diffusers 0.24.0 quirk: token row (b, s) of the GLOBAL batch takes the

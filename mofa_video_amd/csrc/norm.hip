@@ -282,8 +282,9 @@ extern "C" int mofa_affine_act_f16(const void* x, const float* scale, const floa
 // The summation tree depends only on (fps, nparts): bit-identical run to run and across workgroups of one set.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x, const float* __restrict__ part,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       f16* __restrict__ y, int HW, int C, int ldx, int ldy, int fps, int nparts,
-                                                       int rows_per_wg, float eps, int silu) {
+                                                       f16* __restrict__ y, int HW, int C, int ldx, int ldy, int fps, int total,
+                                                       double cnt, int rows_per_wg, float eps, int silu) {
+    // fps frames share one statistics set of `total` partial entries (consecutive in `part`) over `cnt` elements per group
     extern __shared__ __attribute__((aligned(16))) char gn_smem[];
     float* sScale = (float*)gn_smem;                         // [C]
     float* sShift = sScale + C;                              // [C]
@@ -294,8 +295,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     {
         // 16 threads per entry (16 B = 2 groups x {s, q} each), 16 entries per sweep, 4 sweeps in flight
         const int slot = tid & 15, el = tid >> 4;
-        const f32x4* p0 = (const f32x4*)(part + (size_t)stat * fps * nparts * 64) + slot;
-        const int total = fps * nparts;
+        const f32x4* p0 = (const f32x4*)(part + (size_t)stat * total * 64) + slot;
         double a[4] = {0.0, 0.0, 0.0, 0.0};
         int i = el;
         for (; i + 48 < total; i += 64) {
@@ -322,7 +322,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     __syncthreads();
     if (tid < 32) {
         const double s = dAcc[0][2 * tid], q = dAcc[0][2 * tid + 1];
-        const double cnt = (double)fps * (double)HW * (double)(C / 32);
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
         var = var < 0.0 ? 0.0 : var;
@@ -378,7 +377,28 @@ extern "C" int mofa_gn_apply_f16(const void* x, const float* part, const float* 
     while (rpw > 16 && (long long)cdiv(HW, rpw) * nframes < 1024) rpw = (rpw + 1) / 2;
     const int chunks = cdiv(HW, rpw);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, nframes), dim3(256), (size_t)C * 8, (hipStream_t)stream, (const f16*)x, part,
-                       gamma, beta, (f16*)y, HW, C, ldx, ldy, frames_per_stat, nparts, rpw, eps, silu);
+                       gamma, beta, (f16*)y, HW, C, ldx, ldy, frames_per_stat, frames_per_stat * nparts,
+                       (double)frames_per_stat * (double)HW * (double)(C / 32), rpw, eps, silu);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// Frame-sharded clips (mofa_video_amd/parallel.py): the statistics set spans frames that live on other ranks.  Every rank
+// all-gathers the PARTIALS (a few KB per rank: [frames][nparts][32][2] fp32, zero entries for the padding frames of the
+// shorter shards) and this entry applies the normalisation of that ONE set to the `nframes` frames given -- the rank's own
+// frames, or a halo frame received raw from a neighbour shard: every workgroup combines the `nentries` gathered entries
+// itself in entry order (fp64: the same result on every rank), `count_per_group` = elements per group over the WHOLE clip.
+extern "C" int mofa_gn_apply_gathered_f16(const void* x, const float* part_all, int nentries, double count_per_group,
+                                          const float* gamma, const float* beta, void* y, int nframes, int HW, int C, int ldx,
+                                          int ldy, float eps, int silu, mofa_stream_t stream) {
+    if (!x || !part_all || !gamma || !beta || !y || nframes <= 0 || HW <= 0 || nentries <= 0 || nentries > 4096 ||
+        count_per_group <= 0 || C % 32 != 0 || C % 8 != 0 || C > 4096 || ldx % 8 != 0 || ldy % 8 != 0)
+        return MOFA_EINVAL;
+    int rpw = (65536 + C - 1) / C;
+    while (rpw > 16 && (long long)cdiv(HW, rpw) * nframes < 1024) rpw = (rpw + 1) / 2;
+    const int chunks = cdiv(HW, rpw);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, nframes), dim3(256), (size_t)C * 8, (hipStream_t)stream, (const f16*)x, part_all,
+                       gamma, beta, (f16*)y, HW, C, ldx, ldy, nframes, nentries, count_per_group, rpw, eps, silu);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

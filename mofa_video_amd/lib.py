@@ -55,6 +55,7 @@ PROTOTYPES = {
     "mofa_gn_reduce": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_gn_finalize_sums": [_P, _P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P],
     "mofa_gn_apply_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _I, _P],
+    "mofa_gn_apply_gathered_f16": [_P, _P, _I, C.c_double, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "mofa_affine_act_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_layernorm_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _I, _I, _P],
     "mofa_axpby_f32": [_P, _P, _L, _F, _F, _P],

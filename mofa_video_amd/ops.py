@@ -206,10 +206,7 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
 GN_FUSED_MAX_ENTRIES = 512     # partial entries (256 B each) a statistics set may have for the two-launch GroupNorm
 
 
-def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None, reduce_fn=None,
-               frames_total=None):
-    """reduce_fn(sums fp64 [nstat,32,2]) -> all-reduced sums: used when the frames of a statistics set are sharded
-    over ranks (frames_total = number of frames of the set across all ranks)."""
+def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None):
     lib = L.load()
     _chk(x, F16)
     Cc = C_ if C_ is not None else x.shape[1]
@@ -220,26 +217,44 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
     L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part), nframes, HW, Cc, _ld(x), st), "mofa_gn_partial_f16")
     if out is None:
         out = torch.empty((x.shape[0], Cc), dtype=F16, device=x.device)
-    if reduce_fn is None and frames_per_stat * nparts <= GN_FUSED_MAX_ENTRIES:
+    if frames_per_stat * nparts <= GN_FUSED_MAX_ENTRIES:
         # two launches: the applying kernel combines the partial sums of its statistics set itself
         L.check(lib.mofa_gn_apply_f16(L.ptr(x), L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(out), nframes, HW, Cc, _ld(x),
                                       _ld(out), frames_per_stat, eps, 1 if silu else 0, st), "mofa_gn_apply_f16")
         return out
     scale = torch.empty((nframes, Cc), dtype=F32, device=x.device)
     shift = torch.empty((nframes, Cc), dtype=F32, device=x.device)
-    if reduce_fn is None:
-        L.check(lib.mofa_gn_finalize(L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes, HW,
-                                     Cc, frames_per_stat, eps, st), "mofa_gn_finalize")
-    else:
-        nstat = nframes // frames_per_stat
-        sums = torch.empty((nstat, 32, 2), dtype=torch.float64, device=x.device)
-        L.check(lib.mofa_gn_reduce(L.ptr(part), L.ptr(sums), nframes, HW, Cc, frames_per_stat, st), "mofa_gn_reduce")
-        sums = reduce_fn(sums)
-        cnt = float(frames_total) * HW * (Cc // 32)
-        L.check(lib.mofa_gn_finalize_sums(L.ptr(sums), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes,
-                                          Cc, frames_per_stat, cnt, eps, L.stream_ptr()), "mofa_gn_finalize_sums")
+    L.check(lib.mofa_gn_finalize(L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift), nframes, HW,
+                                 Cc, frames_per_stat, eps, st), "mofa_gn_finalize")
     L.check(lib.mofa_affine_act_f16(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(out), nframes, HW, Cc, _ld(x), _ld(out),
                                     1 if silu else 0, st), "mofa_affine_act_f16")
+    return out
+
+
+# GroupNorm whose statistics set spans frames on other ranks (parallel.FrameParallel): partials into the rank's rows of the
+# gather buffer, [all-gather by the caller], then one applying launch per group of frames (own frames, received halo frames)
+def gn_nparts(HW, Cc):
+    return L.load().mofa_gn_nparts(HW, Cc)
+
+
+def gn_partial_into(x, part_rows, nframes, HW):
+    """part_rows: fp32 [nframes * nparts, 64] rows of the gather buffer (contiguous)"""
+    lib = L.load()
+    _chk(x, F16); _chk(part_rows, F32)
+    assert x.shape[0] == nframes * HW and part_rows.is_contiguous()
+    assert part_rows.shape[0] == nframes * lib.mofa_gn_nparts(HW, x.shape[1]) and part_rows.shape[1] == 64
+    L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part_rows), nframes, HW, x.shape[1], _ld(x), L.stream_ptr()),
+            "mofa_gn_partial_f16")
+
+
+def gn_apply_gathered(x, part_all, count_per_group, gamma, beta, eps, out, nframes, HW, silu=False):
+    """normalise ``nframes`` frames of x with the ONE statistics set whose gathered partial entries are ``part_all``"""
+    lib = L.load()
+    _chk(x, F16); _chk(out, F16); _chk(part_all, F32)
+    assert x.shape[0] == nframes * HW == out.shape[0] and part_all.is_contiguous()
+    L.check(lib.mofa_gn_apply_gathered_f16(L.ptr(x), L.ptr(part_all), part_all.shape[0], float(count_per_group), L.ptr(gamma),
+                                           L.ptr(beta), L.ptr(out), nframes, HW, x.shape[1], _ld(x), _ld(out), eps,
+                                           1 if silu else 0, L.stream_ptr()), "mofa_gn_apply_gathered_f16")
     return out
 
 

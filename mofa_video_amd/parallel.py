@@ -4,8 +4,14 @@ Layout for N ranks (N in 1, 2, 4, 8, ...):  2-way CFG x (N/2)-way frames.
     rank r:  half = r // frame_ranks  (0 = unconditional, 1 = conditional)   [N == 1: both halves on the one rank]
              shard = r %  frame_ranks -> frames [f0, f1) of the clip (contiguous, sizes differ by at most 1)
 Weights are replicated.  Exchanges inside one denoise step (RCCL over xGMI through torch.distributed):
-    * temporal GroupNorm (statistics span all T frames): all-reduce of fp64 [32][2] partial sums   (frame group)
-    * temporal (3,1,1) convolution: one halo frame from each neighbour shard (batched p2p)        (frame group)
+    * temporal GroupNorm + (3,1,1) convolution (twice per TemporalResnetBlock), ONE exchange group each:
+        - the RAW boundary frames of the block's input go to the neighbour shards asynchronously (batched p2p on the "data"
+          communicator) as soon as that input exists,
+        - the shard's GroupNorm partials (a few KB) are all-gathered on the "ctl" communicator -- the only point of the group
+          the compute stream waits for --, every rank combines all partials itself in entry order (bit-identical statistics
+          on every rank, no reduction-order dependence) and normalises its own frames,
+        - the convolution of the INTERIOR frames runs while the boundary frames travel; they are normalised on arrival with
+          the same statistics and the two boundary frames are convolved last.
     * temporal self-attention: ONE all_gather_into_tensor of the normed hidden tokens (C columns; r02 gathered K|V = 2C) into
       a preallocated [frame_ranks x T_max frames] buffer (the LayerNorm writes this rank's slot in place, the collective runs
       asynchronously under the Q projection, every rank then projects K|V for all key slots, and the attention kernel masks
@@ -14,6 +20,11 @@ Weights are replicated.  Exchanges inside one denoise step (RCCL over xGMI throu
 and once per clip: all-gather of the final latents before the VAE decode, whose chunks are independent and are
 dealt round-robin to ALL ranks.  Everything per-frame (2-D convs, spatial norms/attention, FFs, the adapter warps,
 zero convs, the Euler step) needs no communication.
+
+With two networks of a step in flight (adapter trunk || UNet encoder, one host thread and HIP stream each) the exchange
+groups are issued in ONE global order on every rank -- trunk's k-th, encoder's k-th, ... -- enforced by ``TurnToken``: a
+collective is only ever issued by the thread that holds the token, so no two ranks can disagree about the order on any
+communicator (the precondition for RCCL not to deadlock) whatever the host timing is.
 
 ``Comm`` implementations: ``TorchComm`` (torch.distributed: "nccl" = RCCL on the GPUs, "gloo" in the CPU tests) and
 ``ThreadComm`` (virtual ranks as threads of one process -- lets the whole sharded HIP path be checked against the
@@ -82,8 +93,15 @@ class TorchComm:
             for g in (tuple(lay.frame_group), tuple(lay.pair_group)):
                 if g not in seen:
                     seen.append(g)
+        # per group of ranks three communicators, so that a small latency-bound exchange never queues behind a bulk transfer of
+        # the other network of the step: "" = bulk (token gather, final latents, CFG pair), "ctl" = GroupNorm partials,
+        # "data" = halo frames.  Created by every rank in the same order (a torch.distributed requirement).
+        self._ctl, self._data = {}, {}
         for g in seen:
-            self._groups[g] = dist.new_group(list(g)) if len(g) > 1 else None
+            many = len(g) > 1
+            self._groups[g] = dist.new_group(list(g)) if many else None
+            self._ctl[g] = dist.new_group(list(g)) if many else None
+            self._data[g] = dist.new_group(list(g)) if many else None
         self._world_group = None
 
     def _g(self, ranks):
@@ -120,25 +138,43 @@ class TorchComm:
         return self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=self._g(ranks),
                                                 async_op=True)
 
-    def exchange_halo(self, first, last, prev_rank, next_rank):
-        """send `first` to prev and `last` to next; receive prev's last and next's first (None at the clip ends)"""
+    def gather_small_into(self, buf, slot_rows, ranks):
+        """the in-place all-gather of ``all_gather_into`` on the "ctl" communicator, complete in stream order when it returns
+        (the current stream waits for it; the host does not block on RCCL)"""
+        if len(ranks) > 1:
+            i = list(ranks).index(self.rank)
+            self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=self._ctl[tuple(ranks)])
+        return buf
+
+    def halo_begin(self, first, last, prev_rank, next_rank, ranks):
+        """send `first` to prev and `last` to next; receive prev's last and next's first (None at the clip ends).
+        Asynchronous (the "data" communicator's stream): ``wait()`` -> (from_prev, from_next) makes the current stream wait."""
         dist = self.dist
+        grp = self._data[tuple(ranks)]
         ops, from_prev, from_next = [], None, None
         if prev_rank is not None:
             from_prev = torch.empty_like(last)
-            ops += [dist.P2POp(dist.isend, first.contiguous(), prev_rank), dist.P2POp(dist.irecv, from_prev, prev_rank)]
+            ops += [dist.P2POp(dist.isend, first.contiguous(), prev_rank, group=grp), dist.P2POp(dist.irecv, from_prev, prev_rank, group=grp)]
         if next_rank is not None:
             from_next = torch.empty_like(first)
-            ops += [dist.P2POp(dist.isend, last.contiguous(), next_rank), dist.P2POp(dist.irecv, from_next, next_rank)]
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        return from_prev, from_next
+            ops += [dist.P2POp(dist.isend, last.contiguous(), next_rank, group=grp), dist.P2POp(dist.irecv, from_next, next_rank, group=grp)]
+        return _HaloWork(dist.batch_isend_irecv(ops) if ops else [], from_prev, from_next, (first, last))
 
 
 class _Done:
     def wait(self):
         return True
+
+
+class _HaloWork:
+    def __init__(self, works, from_prev, from_next, keep=None):
+        self.works, self.res, self.keep = works, (from_prev, from_next), keep   # keep: the send buffers stay alive until wait()
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        self.works, self.keep = [], None
+        return self.res
 
 
 class ThreadWorld:
@@ -160,14 +196,30 @@ class ThreadWorld:
 
 
 class ThreadComm:
+    """Virtual ranks as threads of one process on ONE GPU (the sharded HIP path checked against the unsharded one without a
+    multi-GPU node).  The ranks' launches may sit on different HIP streams (every rank's second network has a stream of its
+    own), so an exchange is: drain my stream, publish, barrier, copy the peers' tensors on my stream, drain, barrier -- host
+    synchronous throughout, which is fine for a checker transport and makes every hand-over race free."""
+
     def __init__(self, tworld, rank):
         self.tw, self.rank = tworld, rank
 
+    @staticmethod
+    def _drain(t):
+        ts = t if isinstance(t, (tuple, list)) else (t,)
+        if any(x is not None and x.is_cuda for x in ts):
+            torch.cuda.current_stream().synchronize()
+
     def _exchange(self, t, ranks):
+        """-> the tensors (or tuples of tensors) every rank of ``ranks`` published, in rank order, as private copies"""
         bar, slots = self.tw._group_state(ranks)
-        slots[list(ranks).index(self.rank)] = t
+        i = list(ranks).index(self.rank)
+        self._drain(t)
+        slots[i] = t
         bar.wait()
-        got = list(slots)
+        cp = lambda x: None if x is None else x.clone()       # noqa: E731
+        got = [(tuple(cp(x) for x in g) if isinstance(g, (tuple, list)) else cp(g)) if j != i else g for j, g in enumerate(slots)]
+        self._drain(t)
         bar.wait()
         return got
 
@@ -184,7 +236,7 @@ class ThreadComm:
     def all_gather(self, t, ranks):
         if len(ranks) == 1:
             return [t]
-        return [g.clone() for g in self._exchange(t.contiguous(), ranks)]
+        return self._exchange(t.contiguous(), ranks)
 
     def all_gather_world(self, t):
         return self.all_gather(t, list(range(self.tw.world)))
@@ -197,23 +249,103 @@ class ThreadComm:
         for j, g in enumerate(got):
             if j != i:
                 buf[j * slot_rows:(j + 1) * slot_rows].copy_(g)
-        if buf.is_cuda:
-            torch.cuda.current_stream().synchronize()      # the peers' slots must stay put until they were read
-        bar, _ = self.tw._group_state(ranks)
-        bar.wait()
         return _Done()
+
+    def gather_small_into(self, buf, slot_rows, ranks):
+        self.all_gather_into(buf, slot_rows, ranks)
+        return buf
+
+    def halo_begin(self, first, last, prev_rank, next_rank, ranks):
+        if len(ranks) == 1:
+            return _HaloWork([], None, None)
+        got = self._exchange((first, last), ranks)
+        ranks = list(ranks)
+        from_prev = got[ranks.index(prev_rank)][1] if prev_rank is not None else None
+        from_next = got[ranks.index(next_rank)][0] if next_rank is not None else None
+        return _HaloWork([], from_prev, from_next)
 
 
 # ---------------------------------------------------------------------------------------------------------
+class TurnToken:
+    """Issue order of the exchange groups of TWO networks that one rank enqueues from two host threads (adapter trunk = role 0
+    on the second HIP stream, UNet encoder = role 1 on the caller's): a thread issues collectives only while it holds the
+    token, passes it on after every exchange group and gets it back after the other thread's next group -- trunk's k-th, then
+    encoder's k-th, ... -- and a thread that has finished hands it over for good.  The resulting global order depends on the
+    program alone (both threads run the same code on every rank), never on host timing, so all ranks issue the same sequence
+    on every communicator: the condition under which RCCL cannot deadlock.  ``log`` records (role, tag) per group (tests)."""
+
+    def __init__(self, first=0, timeout=600.0, enforce=True):
+        self.cv = threading.Condition()
+        self.holder, self.active, self.timeout, self.enforce = first, [True, True], timeout, enforce
+        self.log = []
+
+    def acquire(self, role):
+        if not self.enforce:                                   # (tests: what the log looks like WITHOUT the token)
+            return
+        with self.cv:
+            while self.holder != role and self.active[1 - role]:
+                if not self.cv.wait(self.timeout):
+                    raise RuntimeError(f"turn token: role {role} waited {self.timeout} s for its turn (the other network's "
+                                       "thread died or issued fewer exchange groups than this rank's peers expect)")
+            self.holder = role
+
+    def release(self, role, tag=None):
+        with self.cv:
+            self.log.append((role, tag))
+            if self.enforce and self.active[1 - role]:
+                self.holder = 1 - role
+            self.cv.notify_all()
+
+    def finish(self, role):
+        with self.cv:
+            self.active[role] = False
+            if self.holder == role:
+                self.holder = 1 - role
+            self.cv.notify_all()
+
+
+class _Turn:
+    def __init__(self, tok, role, tag):
+        self.tok, self.role, self.tag = tok, role, tag
+
+    def __enter__(self):
+        if self.tok is not None:
+            self.tok.acquire(self.role)
+
+    def __exit__(self, *exc):
+        if self.tok is not None:
+            self.tok.release(self.role, self.tag)
+        return False
+
+
 class FrameParallel:
     """The per-rank object blocks consult (``Ctx.par``) when a clip's frames are sharded."""
 
     def __init__(self, layout, comm, p2p=True):
         self.lay, self.comm = layout, comm
         self.T_full, self.T_loc, self.f0, self.f1 = layout.T, layout.T_loc, layout.f0, layout.f1
-        self.p2p = p2p and isinstance(comm, TorchComm)
+        self.p2p = p2p
         self.kv_inplace = True      # temporal attention K|V: in-place asynchronous all_gather_into_tensor (else: compacting gather)
         self.gather_hidden = True   # ... of the normed hidden tokens (C columns; K|V projected after the gather) instead of K|V (2C)
+        self.two_streams = True     # adapter trunk || UNet encoder on two host threads / HIP streams under a TurnToken
+        self.split_convs = True     # (3,1,1) convolutions as interior + boundary launches (the halo frames travel meanwhile)
+        self._tls = threading.local()
+        self._part_bufs = {}
+
+    # two networks in flight: issue order of their exchange groups --------------------------------------------
+    def bind(self, token, role):
+        """this host thread enqueues network ``role`` (0 = adapter trunk, 1 = UNet encoder) under ``token``"""
+        self._tls.token, self._tls.role = token, role
+
+    def unbind(self):
+        tok, role = getattr(self._tls, "token", None), getattr(self._tls, "role", 0)
+        self._tls.token = None
+        if tok is not None:
+            tok.finish(role)
+
+    def turn(self, tag=None):
+        """context of ONE exchange group: entered when it is this thread's turn, passes the token on when left"""
+        return _Turn(getattr(self._tls, "token", None), getattr(self._tls, "role", 0), tag)
 
     def self_check(self, device):
         """Runs the two transport-specific fast paths once on small known data -- the in-place asynchronous
@@ -263,7 +395,7 @@ class FrameParallel:
             ok = 1.0
             try:
                 first, last = pattern(lay.shard, rows), pattern(lay.shard, rows) + 1024.0
-                fp, fn = self.comm.exchange_halo(first, last, lay.prev_rank, lay.next_rank)
+                fp, fn = self.comm.halo_begin(first, last, lay.prev_rank, lay.next_rank, grp).wait()
                 if lay.prev_rank is not None and not torch.equal(fp, pattern(lay.shard - 1, rows) + 1024.0):
                     ok = 0.0
                 if lay.next_rank is not None and not torch.equal(fn, pattern(lay.shard + 1, rows)):
@@ -278,35 +410,38 @@ class FrameParallel:
                 report["halo"] = "all_gather (the batched p2p path failed its self-check)"
         return report
 
-    # temporal GroupNorm -----------------------------------------------------------------------------------
-    def reduce_gn(self, sums):
-        return self.comm.all_reduce_sum(sums, self.lay.frame_group)
+    # temporal GroupNorm statistics ----------------------------------------------------------------------------
+    def part_buffer(self, nparts, device):
+        """-> (buf fp32 [frame_ranks * T_max * nparts, 64], own = this shard's [T_loc * nparts, 64] rows of it): the gather
+        buffer of the GroupNorm partials of one clip (one entry of 32 x {sum, sum of squares} per frame and row chunk).
+        Cached per (network role, stream, nparts) and zero-filled once: ``mofa_gn_partial_f16`` rewrites the own rows every
+        time, the padding rows of a shorter shard stay zero (they are gathered and summed like any entry)."""
+        lay = self.lay
+        key = (getattr(self._tls, "role", 0), torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0, nparts,
+               str(device))
+        buf = self._part_bufs.get(key)
+        if buf is None:
+            buf = torch.zeros((lay.frame_ranks * lay.T_max * nparts, 64), dtype=torch.float32, device=device)
+            self._part_bufs[key] = buf
+        r0 = lay.shard * lay.T_max * nparts
+        return buf, buf[r0:r0 + self.T_loc * nparts]
+
+    def gather_partials(self, buf, nparts):
+        """all ranks' partials into ``buf`` (in place; complete in stream order on return)"""
+        return self.comm.gather_small_into(buf, self.lay.T_max * nparts, self.lay.frame_group)
 
     # temporal conv halo -----------------------------------------------------------------------------------
-    def halo(self, x, HW):
-        """x [T_loc*HW, C] -> [(T_loc+2)*HW, C]: neighbour shards' boundary frames before/after, zeros at clip ends
-        (= the conv's zero padding)."""
+    def halo_begin(self, x, HW):
+        """x [T_loc*HW, C]: starts the exchange of its first / last frame with the neighbour shards.  ``wait()`` ->
+        (frame before this shard, frame after it), None at the clip ends (= the convolution's zero padding)."""
         lay = self.lay
-        C = x.shape[1]
-        ext = torch.empty(((self.T_loc + 2) * HW, C), dtype=x.dtype, device=x.device)
-        ext[HW:(self.T_loc + 1) * HW].copy_(x)
         first, last = x[:HW], x[(self.T_loc - 1) * HW:]
         if self.p2p:
-            fp, fn = self.comm.exchange_halo(first, last, lay.prev_rank, lay.next_rank)
-        else:
-            both = torch.cat([first, last], 0)
-            got = self.comm.all_gather(both, lay.frame_group)
-            fp = got[lay.shard - 1][HW:] if lay.prev_rank is not None else None
-            fn = got[lay.shard + 1][:HW] if lay.next_rank is not None else None
-        if fp is not None:
-            ext[:HW].copy_(fp)
-        else:
-            ext[:HW].zero_()
-        if fn is not None:
-            ext[(self.T_loc + 1) * HW:].copy_(fn)
-        else:
-            ext[(self.T_loc + 1) * HW:].zero_()
-        return ext
+            return self.comm.halo_begin(first, last, lay.prev_rank, lay.next_rank, lay.frame_group)
+        got = self.comm.all_gather(torch.cat([first, last], 0), lay.frame_group)      # conservative path (self_check)
+        fp = got[lay.shard - 1][HW:] if lay.prev_rank is not None else None
+        fn = got[lay.shard + 1][:HW] if lay.next_rank is not None else None
+        return _HaloWork([], fp, fn)
 
     # temporal attention K/V ---------------------------------------------------------------------------------
     @property

@@ -122,8 +122,8 @@ class FlowControlNetPipeline:
         """``adapters``: [(controlnet, its Ctx, its per-clip condition, conditioning scale)], one entry, or two (face, drag)
         whose residuals are blended by ``masks`` (Hybrid/pipeline/pipeline.py:479-489) -> the UNet's noise prediction (tokens).
         Without frame sharding the trunks run on ``self._adapter_stream`` while the UNet's encoder half runs on the caller's
-        stream; the streams join before the residuals are added (unet.decode_tokens).  Frame-sharded ranks keep one stream:
-        their exchanges (halo, GroupNorm sums, token gather) are ordered by the host's issue order on the transport's stream."""
+        stream; the streams join before the residuals are added (unet.decode_tokens).  Frame-sharded ranks do the same with a
+        second host thread and a turn token that fixes the issue order of their exchanges (_denoise_forward_sharded)."""
         unet = self.unet
 
         def trunks():
@@ -136,10 +136,12 @@ class FlowControlNetPipeline:
                 down, mid = _blend_residuals(down, mid, res[1][0], res[1][1], masks, Bl * Tl)
             return down, mid
 
-        if fpar is not None or not self.overlap_adapter:
+        if not self.overlap_adapter or (fpar is not None and not fpar.two_streams):
             down, mid = trunks()
             unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
             return unet.forward_tokens(x_loc, c_un, h, w, down, mid)
+        if fpar is not None:
+            return self._denoise_forward_sharded(trunks, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, c_un)
         cur = torch.cuda.current_stream(self.device)
         if self._adapter_stream is None:
             self._adapter_stream = torch.cuda.Stream(device=self.device)
@@ -176,6 +178,50 @@ class FlowControlNetPipeline:
         cur.wait_stream(side)
         outs[1].record_stream(cur)
         return torch.cat(outs, 0)
+
+    def _denoise_forward_sharded(self, trunks, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, c_un):
+        """Frame-sharded ranks: trunk(s) and UNet encoder still overlap on two HIP streams, but both issue collectives, and all
+        ranks must issue them in one order.  The trunk is therefore enqueued by a second HOST THREAD on the second stream and
+        the two threads take turns at every exchange group under a ``parallel.TurnToken`` (trunk's k-th, encoder's k-th, ...):
+        each network's wait for its GroupNorm partials / halo frames / token gather is covered by the other network's kernels.
+        The decoder half runs on the caller's stream alone, as on a single GPU."""
+        import threading
+        from .parallel import TurnToken
+        unet, dev = self.unet, self.device
+        cur = torch.cuda.current_stream(dev)
+        if self._adapter_stream is None:
+            self._adapter_stream = torch.cuda.Stream(device=dev)
+        side = self._adapter_stream
+        side.wait_stream(cur)
+        tok = TurnToken(first=0)
+        box = {}
+
+        def trunk_thread():
+            try:
+                torch.cuda.set_device(dev)
+                fpar.bind(tok, 0)
+                with torch.no_grad(), torch.cuda.stream(side):
+                    box["res"] = trunks()
+            except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+                box["err"] = e
+            finally:
+                fpar.unbind()
+        th = threading.Thread(target=trunk_thread, name="mofa-adapter-trunk")
+        th.start()
+        try:
+            fpar.bind(tok, 1)
+            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+            enc = unet.encode_tokens(x_loc, c_un, h, w)
+        finally:
+            fpar.unbind()
+            th.join()
+        if "err" in box:
+            raise box["err"]
+        down, mid = box["res"]
+        cur.wait_stream(side)
+        for r in list(down) + [mid]:
+            r.record_stream(cur)
+        return unet.decode_tokens(enc, c_un, down, mid)
 
     # ---- pieces of the reference __call__ ---------------------------------------------------------------------------------
     def check_inputs(self, image, height, width):                      # pipeline.py:222-234

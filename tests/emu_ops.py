@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY: a torch-CPU stand-in for the subset of ``mofa_video_amd.ops`` that the front-end host code
-calls, so that the *host logic* (weight repacking into 128-column head slots, the key-padding mask column, quant_conv
+and the frame-sharded temporal block call, so that the *host logic* (the exchange protocol of parallel.FrameParallel, weight repacking into 128-column head slots, the key-padding mask column, quant_conv
 folded into conv_out, trailing-pad geometry, buffer views) can be exercised without a GPU in the ``-m "not gpu"`` suite.
-It is installed by monkeypatching inside tests/test_frontend_host_cpu.py and nowhere else; the product has no CPU path
+It is installed by monkeypatching inside tests/test_frontend_host_cpu.py and the worker processes of tests/test_parallel_gloo.py only; the product has no CPU path
 (mofa_video_amd/lib.py raises without libmofa_hip.so, and these functions are never importable from the package)."""
 import torch
 import torch.nn.functional as F
@@ -33,7 +33,18 @@ def igemm(x, w, bias=None, geom=None, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30)
         assert tuple(y.shape[-2:]) == (geom.Hout, geom.Wout), (y.shape, geom.Hout, geom.Wout)
         y = y.permute(0, 2, 3, 1).reshape(-1, N)
     else:
-        raise NotImplementedError("temporal conv is not used by the front end")
+        # (3,1,1) convolution over frames of HW rows.  T > 0: clips of T frames, zero padding at the clip ends; T == 0: unclipped,
+        # the caller supplies one halo frame before and after a.x (the frame-sharded path: x is a view into a longer buffer)
+        Cin, HW = Ktot // 3, geom.HW
+        Mr = M if M is not None else x.shape[0]
+        wk = wf.reshape(N, 3, Cin)
+        if geom.T == 0:
+            xe = torch.as_strided(x, (Mr + 2 * HW, Cin), (x.stride(0), 1), x.storage_offset() - HW * x.stride(0)).float()
+            y = sum(xe[k * HW:k * HW + Mr] @ wk[:, k].T for k in range(3))
+        else:
+            xc = x[:Mr, :Cin].float().reshape(-1, geom.T, HW, Cin)
+            xp = F.pad(xc, (0, 0, 0, 0, 1, 1))
+            y = sum(xp[:, k:k + geom.T].reshape(Mr, Cin) @ wk[:, k].T for k in range(3))
     if M is not None:
         y = y[:M]
     M = y.shape[0]
@@ -70,13 +81,42 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
     return F.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps).to(F16)
 
 
-def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None, reduce_fn=None,
-               frames_total=None):
-    assert frames_per_stat == 1 and reduce_fn is None
+def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None):
+    assert frames_per_stat == 1
     C = gamma.numel()
     y = F.group_norm(x[:, :C].float().reshape(nframes, HW, C).permute(0, 2, 1), 32, gamma, beta, eps)
     y = F.silu(y) if silu else y
     return y.permute(0, 2, 1).reshape(nframes * HW, C).to(F16)
+
+
+def gn_nparts(HW, Cc):
+    """csrc/norm.hip gn_nchunks"""
+    n, cap = (-(-HW // 576), 128) if HW >= 9216 else (-(-HW // 144), 16)
+    return max(1, min(n, cap))
+
+
+def gn_partial_into(x, part_rows, nframes, HW):
+    C = x.shape[1]
+    nparts = gn_nparts(HW, C)
+    rpc = -(-HW // nparts)
+    xf = x.float().reshape(nframes, HW, 32, C // 32)
+    for f in range(nframes):
+        for ch in range(nparts):
+            blk = xf[f, ch * rpc:(ch + 1) * rpc]
+            part_rows[f * nparts + ch] = torch.stack([blk.sum((0, 2)), (blk * blk).sum((0, 2))], -1).reshape(64)
+
+
+def gn_apply_gathered(x, part_all, count_per_group, gamma, beta, eps, out, nframes, HW, silu=False):
+    C = x.shape[1]
+    tot = part_all.double().reshape(-1, 32, 2).sum(0)
+    mean = tot[:, 0] / count_per_group
+    var = (tot[:, 1] / count_per_group - mean * mean).clamp_min(0.0)
+    rstd = 1.0 / torch.sqrt(var + eps)
+    cpg = C // 32
+    sc = rstd.float().repeat_interleave(cpg) * gamma
+    y = x.float() * sc + (beta - mean.float().repeat_interleave(cpg) * sc)
+    out.copy_((F.silu(y) if silu else y).to(F16))
+    return out
 
 
 def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, prescaled=False):
@@ -153,11 +193,15 @@ def resize_nearest_f32(x, h, w):
     return torch.nn.functional.interpolate(x[None].float(), size=(h, w), mode="nearest")[0]
 
 
-NAMES = ["resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
+NAMES = ["gn_nparts", "gn_partial_into", "gn_apply_gathered", "resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
          "tokens_to_nchw", "patchify", "filter1d_reflect", "resize_bicubic_ac"]
 
 
-def install(monkeypatch):
+def install(monkeypatch=None):
+    """monkeypatch=None: plain setattr (spawned test worker processes, which exit afterwards)"""
     from mofa_video_amd import ops
     for n in NAMES:
-        monkeypatch.setattr(ops, n, globals()[n])
+        if monkeypatch is not None:
+            monkeypatch.setattr(ops, n, globals()[n])
+        else:
+            setattr(ops, n, globals()[n])

@@ -13,17 +13,25 @@ def check_frame_exchanges(rank, world, T, HW, C, device):
     full = torch.randn(T * HW, C, generator=g).half().to(device)
     mine = full[lay.f0 * HW:lay.f1 * HW].contiguous()
 
-    ext = par.halo(mine, HW)                                              # neighbour frames / zeros at the clip ends
-    exp_prev = full[(lay.f0 - 1) * HW:lay.f0 * HW] if lay.f0 > 0 else torch.zeros_like(full[:HW])
-    exp_next = full[lay.f1 * HW:(lay.f1 + 1) * HW] if lay.f1 < T else torch.zeros_like(full[:HW])
-    assert torch.equal(ext[:HW], exp_prev) and torch.equal(ext[(lay.T_loc + 1) * HW:], exp_next)
-    assert torch.equal(ext[HW:(lay.T_loc + 1) * HW], mine)
+    fp, fn = par.halo_begin(mine, HW).wait()                              # neighbour frames / None at the clip ends
+    if str(device) != "cpu":
+        torch.cuda.synchronize()
+    assert (fp is None) == (lay.f0 == 0) and (fn is None) == (lay.f1 == T)
+    if fp is not None:
+        assert torch.equal(fp, full[(lay.f0 - 1) * HW:lay.f0 * HW])
+    if fn is not None:
+        assert torch.equal(fn, full[lay.f1 * HW:(lay.f1 + 1) * HW])
 
-    sums = torch.stack([mine.double().sum(0), (mine.double() ** 2).sum(0)], -1)[:32].reshape(1, -1, 2).clone()
-    red = par.reduce_gn(sums)
-    parts = [full[a * HW:b * HW] for a, b in lay.bounds]
-    fs = sum(torch.stack([p.double().sum(0), (p.double() ** 2).sum(0)], -1)[:32].reshape(1, -1, 2) for p in parts)
-    assert torch.allclose(red, fs, rtol=1e-12)
+    pbuf, pown = par.part_buffer(2, torch.device(device))                 # GroupNorm partials: gathered, padding rows zero
+    pown.copy_(torch.arange(lay.T_loc * 2 * 64, dtype=torch.float32, device=device).reshape(-1, 64) + 1000.0 * lay.shard)
+    par.gather_partials(pbuf, 2)
+    if str(device) != "cpu":
+        torch.cuda.synchronize()
+    for s_, (a, b) in enumerate(lay.bounds):
+        rows = pbuf[s_ * lay.T_max * 2:(s_ * lay.T_max + b - a) * 2]
+        exp = torch.arange((b - a) * 2 * 64, dtype=torch.float32, device=device).reshape(-1, 64) + 1000.0 * s_
+        assert torch.equal(rows, exp), (rank, s_)
+        assert not pbuf[(s_ * lay.T_max + b - a) * 2:(s_ + 1) * lay.T_max * 2].any()
 
     buf, own = par.kv_buffer(HW, C, device)                               # in-place all_gather_into_tensor + key mask
     buf.fill_(float("nan"))

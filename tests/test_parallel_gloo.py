@@ -56,21 +56,33 @@ def _worker(rank, world, port, T, HW, C):
         h = lay.half if lay.half is not None else 0
         mine = full[h, lay.f0 * HW:lay.f1 * HW].contiguous()
 
-        # 1. halo exchange reproduces the zero-padded (3,1,1) convolution of the whole clip
+        # 1. halo exchange (asynchronous begin / wait) reproduces the zero-padded (3,1,1) convolution of the whole clip
         w = torch.randn(C, C, 3, 1, 1, generator=g)
         x5 = full[h].reshape(1, T, HW, C).permute(0, 3, 1, 2).unsqueeze(-1)          # [1,C,T,HW,1]
         ref = F.conv3d(x5, w, padding=(1, 0, 0))[0, :, lay.f0:lay.f1, :, 0]             # [C, T_loc, HW]
-        ext = par.halo(mine, HW)
-        assert ext.shape[0] == (lay.T_loc + 2) * HW
+        fp, fn = par.halo_begin(mine, HW).wait()
+        assert (fp is None) == (lay.f0 == 0) and (fn is None) == (lay.f1 == T)
+        z = torch.zeros(HW, C)
+        ext = torch.cat([z if fp is None else fp, mine, z if fn is None else fn], 0)
         e5 = ext.reshape(1, lay.T_loc + 2, HW, C).permute(0, 3, 1, 2).unsqueeze(-1)
         got = F.conv3d(e5, w)[0, :, :, :, 0]                                             # valid conv over the halo'd shard
         assert torch.allclose(got, ref, atol=1e-4), (rank, (got - ref).abs().max())
 
-        # 2. temporal GroupNorm statistics: all-reduced partial sums == sums over the whole clip
-        sums = torch.stack([mine.double().sum(0), (mine.double() ** 2).sum(0)], -1)[:32].reshape(1, -1, 2).clone()
-        red = par.reduce_gn(sums.clone())
-        fs = torch.stack([full[h].double().sum(0), (full[h].double() ** 2).sum(0)], -1)[:32].reshape(1, -1, 2)
-        assert torch.allclose(red, fs, rtol=1e-12)
+        # 2. temporal GroupNorm statistics: the gathered partials (zero rows for the padding frames of shorter shards) sum to the
+        #    sums over the whole clip, identically on every rank; the buffer is cached and its padding rows stay zero
+        for rep in range(2):
+            buf, own = par.part_buffer(3, mine.device)
+            assert own.shape == (lay.T_loc * 3, 64) and buf.shape == (lay.frame_ranks * lay.T_max * 3, 64)
+            fr = mine.reshape(lay.T_loc, HW, C).double()
+            for t in range(lay.T_loc):                                                   # 3 "row chunks" of 2 rows per frame
+                for ch in range(3):
+                    blk = fr[t, ch * 2:(ch + 1) * 2, :32]
+                    own[t * 3 + ch] = torch.stack([blk.sum(0), (blk ** 2).sum(0)], -1).reshape(64).float()
+            par.gather_partials(buf, 3)
+            tot = buf.double().reshape(-1, 32, 2).sum(0)
+            fs = torch.stack([full[h][:, :32].double().sum(0), (full[h][:, :32].double() ** 2).sum(0)], -1)
+            assert torch.allclose(tot, fs, rtol=1e-5, atol=1e-3), (rank, rep, (tot - fs).abs().max())
+            assert par.part_buffer(3, mine.device)[0] is buf
 
         # 3. K|V all-gather along the frame axis (uneven shards are padded and compacted)
         kv = par.gather_frames(mine, HW)
@@ -163,3 +175,130 @@ def test_deal_ready_chunks_prefers_idle_ranks():
     assert _deal_ready_chunks([0, 1, 2, 3, 4, 5], 4, busy_next=[0, 1, 2]) == [(0, 3), (1, 3), (2, 3), (3, 0), (4, 1), (5, 2)]
     assert _deal_ready_chunks([0, 1, 2], 1, busy_next=[0]) == [(0, 0), (1, 0)]      # one GPU: two per round, the rest wait
     assert _deal_ready_chunks([], 8, busy_next=list(range(7))) == []
+
+
+# ---- the sharded temporal block (GroupNorm over the clip + SiLU -> (3,1,1) convolution) end to end on CPU ---------------------
+class _Norm:
+    def __init__(self, C, g):
+        self.g, self.b, self.eps = torch.randn(C, generator=g) * 0.3 + 1.0, torch.randn(C, generator=g) * 0.2, 1e-5
+
+
+class _Conv:
+    def __init__(self, C, g):
+        w = torch.randn(C, C, 3, 1, 1, generator=g) * (3 * C) ** -0.5
+        self.w5 = w.half().float()
+        self.w = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(C, 3 * C).half().contiguous()    # [N][tap][Cin] (weights.pack_conv3d_t3)
+        self.b = torch.randn(C, generator=g) * 0.1
+
+
+def _reference_block(full, norm, conv, T, HW, C, res=None, s_acc=1.0):
+    """GroupNorm(32) over all T*HW positions of the clip + SiLU -> Conv3d (3,1,1), zero padding, (+ residual), plain torch"""
+    x = full.float().reshape(1, T, HW, C).permute(0, 3, 1, 2)                                # [1, C, T, HW]
+    y = F.silu(F.group_norm(x, 32, norm.g, norm.b, norm.eps)).half().float()
+    o = F.conv3d(y.unsqueeze(-1), conv.w5, conv.b, padding=(1, 0, 0))[0, :, :, :, 0]         # [C, T, HW]
+    o = o.permute(1, 2, 0).reshape(T * HW, C) * s_acc
+    return o + res.float() if res is not None else o
+
+
+def _block_worker(rank, world, port, T, HW, C, two_threads):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import threading
+        import time
+        import emu_ops
+        from mofa_video_amd import blocks
+        from mofa_video_amd.parallel import TurnToken
+        emu_ops.install()
+        lay = Layout(world, rank, T, cfg_ranks=1)
+        par = FrameParallel(lay, TorchComm(lambda r: Layout(world, r, T, cfg_ranks=1)))
+        c = blocks.Ctx(1, lay.T_loc)
+        c.par = par
+
+        def network(seed, nblocks, role=None, tok=None, out=None, delay=0.0):
+            g = torch.Generator().manual_seed(seed)
+            if tok is not None:
+                par.bind(tok, role)
+            try:
+                errs = []
+                for k in range(nblocks):
+                    full = (torch.randn(T * HW, C, generator=g) * 1.5 + 0.3).half()
+                    res = torch.randn(T * HW, C, generator=g).half()
+                    n1, c1 = _Norm(C, g), _Conv(C, g)
+                    time.sleep(delay * ((k + rank) % 3))                                       # perturb the host timing per rank
+                    mine, rmine = full[lay.f0 * HW:lay.f1 * HW].contiguous(), res[lay.f0 * HW:lay.f1 * HW].contiguous()
+                    got = blocks._sharded_norm_convt3(n1, c1, mine, c, HW, r1=rmine, s1=1.0, s_acc=0.7)
+                    ref = _reference_block(full, n1, c1, T, HW, C, res, 0.7)[lay.f0 * HW:lay.f1 * HW]
+                    errs.append(float((got.float() - ref).abs().max()))
+                if out is not None:
+                    out[role] = errs
+                return errs
+            finally:
+                if tok is not None:
+                    par.unbind()
+        if not two_threads:
+            for split in (True, False):
+                par.split_convs = split
+                errs = network(7, 3)
+                assert max(errs) < 2e-2, (rank, split, errs)
+        else:
+            # two networks on two host threads, issue order fixed by the turn token; different block counts and per-rank
+            # delays (rank 0 slows its trunk, rank 1 its encoder): without a common order gloo would pair the wrong collectives
+            tok, out = TurnToken(first=0, timeout=120.0), {}
+            th = threading.Thread(target=network, args=(11, 4, 0, tok, out, 0.02 if rank == 0 else 0.0))
+            th.start()
+            network(12, 6, 1, tok, out, 0.02 if rank == 1 else 0.0)
+            th.join()
+            assert max(out[0]) < 2e-2 and max(out[1]) < 2e-2, (rank, out)
+            assert len(out[0]) == 4 and len(out[1]) == 6
+            order = [r for r, _ in tok.log]
+            assert order == [0, 1] * 4 + [1, 1], (rank, order)                                  # trunk k, encoder k, ...; then the rest
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 7), (4, 17), (3, 8)])
+def test_sharded_temporal_block_gloo(world, T):
+    """shards of 4+3 / 5+4+4+4 / 3+3+2 frames: interior + boundary launches where a shard has >= 4 frames, one launch otherwise"""
+    mp.spawn(_block_worker, args=(world, _free_port(), T, 6, 32, False), nprocs=world, join=True)
+
+
+def test_two_networks_turn_token_gloo():
+    mp.spawn(_block_worker, args=(2, _free_port(), 9, 6, 32, True), nprocs=2, join=True)
+
+
+def test_turn_token_order_is_timing_independent():
+    """the issue order of two threads' exchange groups: with the token it is trunk k, encoder k, ... whatever the host timing;
+    without it (enforce=False, the sabotaged order) two 'ranks' with different delays log DIFFERENT orders -- which on a real
+    transport means mismatched collectives"""
+    import threading
+    import time
+    from mofa_video_amd.parallel import TurnToken
+
+    def run(enforce, slow_role):
+        tok = TurnToken(first=0, enforce=enforce, timeout=30.0)
+
+        def net(role, n):
+            for k in range(n):
+                if role == slow_role:
+                    time.sleep(0.01)
+                tok.acquire(role)
+                tok.release(role, k)
+            tok.finish(role)
+        a = threading.Thread(target=net, args=(0, 5))
+        b = threading.Thread(target=net, args=(1, 5))
+        a.start(); b.start(); a.join(); b.join()
+        return [r for r, _ in tok.log]
+    want = [0, 1] * 5
+    assert run(True, 0) == want and run(True, 1) == want and run(True, None) == want
+    assert run(False, 0) != run(False, 1)
+
+
+def test_turn_token_times_out_instead_of_hanging():
+    from mofa_video_amd.parallel import TurnToken
+    tok = TurnToken(first=0, timeout=0.2)
+    with pytest.raises(RuntimeError, match="turn token"):
+        tok.acquire(1)                       # role 0 holds the token and never issues anything
+    tok.finish(0)
+    tok.acquire(1)                           # ... and a finished partner hands it over for good
