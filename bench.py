@@ -322,6 +322,8 @@ def main():
     ap.add_argument("--single-stream", action="store_true",
                     help="every clip in single-stream order (pipeline.overlap_adapter = False): the mode the roofline leg and the "
                          "rocprofv3 kernel statistics are taken in -- kernel durations are exclusive only when nothing runs beside")
+    ap.add_argument("--graph-steps", type=int, default=-1, help="A/B switch: pipeline.graph_steps = 0 | 1 (one captured hipGraph per "
+                    "clip replayed for steps 1 .. 24; default: the pipeline's)")
     ap.add_argument("--split-decoder", type=int, default=-1, help="A/B switch: pipeline.split_decoder = 0 | 1 (default: the pipeline's)")
     ap.add_argument("--lib", default="", help="A/B switch: load this build of libmofa_hip.so instead of the in-tree one "
                     "(same-box comparison of two kernel builds; the path is echoed in config.library)")
@@ -383,6 +385,8 @@ def main():
     pipe.overlap_adapter = not args.single_stream
     if args.split_decoder >= 0:
         pipe.split_decoder = bool(args.split_decoder)
+    if args.graph_steps >= 0:
+        pipe.graph_steps = bool(args.graph_steps)
     for _ in range(args.warmup):
         run_config(pipe, inp, cfg)
     # Roofline leg: HIP events around every implicit-GEMM / attention / softsplat launch of the LAST clip of the timed region
@@ -493,7 +497,7 @@ def main():
                        "streams": ("single stream" if (args.single_stream or (mode == "shard" and cfg != 5 and world > 2)) else
                                    "adapter trunk || UNet encoder, then the decoder's two CFG halves, on two HIP streams; the last timed clip (HIP "
                                    "events) single-stream"),
-                       "clip_ms": clip_ms,
+                       "graph_steps": bool(pipe.graph_steps), "clip_ms": clip_ms,
                        "output_finite": finite, "comm_paths": comm_paths, **({"library": args.lib} if args.lib else {}),
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},
             "roofline": roofline,

@@ -247,6 +247,17 @@ int mofa_prepare_model_input(const float* latents, const float* image_latents, v
  * noise_pred fp16 token-major [2][T][HW][ldn] (uncond first), g_f = gmin + (gmax-gmin)*f/(T-1) */
 int mofa_cfg_euler_step(float* latents, const void* noise_pred, int T, int HW, int ldn,
                         float sigma, float sigma_next, float gmin, float gmax, mofa_stream_t stream);
+/* The same two with the step's scalars read from DEVICE memory: `step_scalars` = one row of a per-clip step table, fp32
+ * [MOFA_STEP_SCALARS] = {sigma, sigma_next, timestep, timestep, 1/sqrt(sigma^2+1), 0, 0, 0} (the scheduler's sigma table
+ * :337-349 uploaded once per clip; columns 2..3 double as the fp32 [2] timestep tensor of mofa_timestep_embedding).  No
+ * host scalar enters a denoise step, so a whole step can be captured in a hipGraph and replayed: mofa_step_select is the
+ * graph's first node -- cur[..] = table[*counter][..]; ++*counter -- and every other node reads `cur`. */
+#define MOFA_STEP_SCALARS 8
+int mofa_prepare_model_input_dev(const float* latents, const float* image_latents, void* out,
+                                 int T, int HW, int ldo, const float* step_scalars, mofa_stream_t stream);
+int mofa_cfg_euler_step_dev(float* latents, const void* noise_pred, int T, int HW, int ldn,
+                            const float* step_scalars, float gmin, float gmax, mofa_stream_t stream);
+int mofa_step_select(const float* table, int* counter, float* cur, int nsteps, mofa_stream_t stream);
 
 
 /* ---- output stage (the step after the path) -------------------------------------------------------------

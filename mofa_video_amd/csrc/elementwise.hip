@@ -189,8 +189,12 @@ extern "C" int mofa_flow_downscale_f32(const float* flow, float* out, int n, int
 }
 
 // ---- scheduler math ---------------------------------------------------------------------------------
+// `scal` != nullptr: the step's scalars come from device memory (a row of the per-clip step table, mofa_hip.h) -- the form a
+// captured hipGraph needs, where by-value arguments would be frozen at capture time
 __global__ void prepare_model_input_kernel(const float* __restrict__ lat, const float* __restrict__ img,
-                                           f16* __restrict__ out, int T, int HW, int ldo, float inv) {
+                                           f16* __restrict__ out, int T, int HW, int ldo, float inv_arg,
+                                           const float* __restrict__ scal) {
+    const float inv = scal ? scal[4] : inv_arg;
     const long long total = 2LL * T * HW;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int p = (int)(i % HW);
@@ -211,13 +215,37 @@ extern "C" int mofa_prepare_model_input(const float* latents, const float* image
     if (!latents || !image_latents || !out || T <= 0 || HW <= 0 || ldo % 8 != 0 || ldo < 8) return MOFA_EINVAL;
     const float inv = 1.0f / sqrtf(sigma * sigma + 1.0f);
     hipLaunchKernelGGL(prepare_model_input_kernel, dim3(ew_blocks(2LL * T * HW)), dim3(256), 0, (hipStream_t)stream,
-                       latents, image_latents, (f16*)out, T, HW, ldo, inv);
+                       latents, image_latents, (f16*)out, T, HW, ldo, inv, (const float*)nullptr);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+extern "C" int mofa_prepare_model_input_dev(const float* latents, const float* image_latents, void* out, int T, int HW,
+                                            int ldo, const float* step_scalars, mofa_stream_t stream) {
+    if (!latents || !image_latents || !out || !step_scalars || T <= 0 || HW <= 0 || ldo % 8 != 0 || ldo < 8) return MOFA_EINVAL;
+    hipLaunchKernelGGL(prepare_model_input_kernel, dim3(ew_blocks(2LL * T * HW)), dim3(256), 0, (hipStream_t)stream,
+                       latents, image_latents, (f16*)out, T, HW, ldo, 0.0f, step_scalars);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
 
-__global__ void cfg_euler_kernel(float* __restrict__ lat, const f16* __restrict__ np, int T, int HW, int ldn, float sigma,
-                                 float sigma_next, float gmin, float gmax) {
+// cur[0 .. MOFA_STEP_SCALARS) = table[*counter][...]; ++*counter: the first node of a captured denoise step
+__global__ void step_select_kernel(const float* __restrict__ table, int* __restrict__ counter, float* __restrict__ cur, int nsteps) {
+    const int i = *counter;
+    const int row = i < nsteps ? i : nsteps - 1;
+    if (threadIdx.x < MOFA_STEP_SCALARS) cur[threadIdx.x] = table[(size_t)row * MOFA_STEP_SCALARS + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) *counter = i + 1;
+}
+extern "C" int mofa_step_select(const float* table, int* counter, float* cur, int nsteps, mofa_stream_t stream) {
+    if (!table || !counter || !cur || nsteps <= 0) return MOFA_EINVAL;
+    hipLaunchKernelGGL(step_select_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, table, counter, cur, nsteps);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+__global__ void cfg_euler_kernel(float* __restrict__ lat, const f16* __restrict__ np, int T, int HW, int ldn, float sigma_arg,
+                                 float sigma_next_arg, float gmin, float gmax, const float* __restrict__ scal) {
+    const float sigma = scal ? scal[0] : sigma_arg, sigma_next = scal ? scal[1] : sigma_next_arg;
     const long long total = (long long)T * HW;
     const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
     const float c_skip = 1.0f / (sigma * sigma + 1.0f);
@@ -244,7 +272,15 @@ extern "C" int mofa_cfg_euler_step(float* latents, const void* noise_pred, int T
                                    float sigma_next, float gmin, float gmax, mofa_stream_t stream) {
     if (!latents || !noise_pred || T <= 0 || HW <= 0 || ldn % 4 != 0 || sigma <= 0.f) return MOFA_EINVAL;
     hipLaunchKernelGGL(cfg_euler_kernel, dim3(ew_blocks((long long)T * HW)), dim3(256), 0, (hipStream_t)stream, latents,
-                       (const f16*)noise_pred, T, HW, ldn, sigma, sigma_next, gmin, gmax);
+                       (const f16*)noise_pred, T, HW, ldn, sigma, sigma_next, gmin, gmax, (const float*)nullptr);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+extern "C" int mofa_cfg_euler_step_dev(float* latents, const void* noise_pred, int T, int HW, int ldn, const float* step_scalars,
+                                       float gmin, float gmax, mofa_stream_t stream) {
+    if (!latents || !noise_pred || !step_scalars || T <= 0 || HW <= 0 || ldn % 4 != 0) return MOFA_EINVAL;
+    hipLaunchKernelGGL(cfg_euler_kernel, dim3(ew_blocks((long long)T * HW)), dim3(256), 0, (hipStream_t)stream, latents,
+                       (const f16*)noise_pred, T, HW, ldn, 1.0f, 0.0f, gmin, gmax, step_scalars);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }

@@ -78,6 +78,9 @@ PROTOTYPES = {
     "mofa_flow_downscale_f32": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_prepare_model_input": [_P, _P, _P, _I, _I, _I, _F, _P],
     "mofa_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],
+    "mofa_prepare_model_input_dev": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "mofa_cfg_euler_step_dev": [_P, _P, _I, _I, _I, _P, _F, _F, _P],
+    "mofa_step_select": [_P, _P, _P, _I, _P],
     "mofa_pool2d_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mofa_resize_bilinear_ac_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "mofa_resize_bilinear_ac_f32": [_P, _P, _I, _I, _I, _I, _I, _P],

@@ -417,11 +417,12 @@ def cast_f32_to_f16(x):
     return y
 
 
-def cast_f16_to_f32(x):
+def cast_f16_to_f32(x, out=None):
     lib = L.load()
     _chk(x, F16)
     assert x.is_contiguous()
-    y = torch.empty(x.shape, dtype=F32, device=x.device)
+    y = torch.empty(x.shape, dtype=F32, device=x.device) if out is None else out
+    assert y.is_contiguous() and y.numel() == x.numel() and y.dtype == F32
     L.check(lib.mofa_cast_f16_to_f32(L.ptr(x), L.ptr(y), x.numel(), L.stream_ptr()), "mofa_cast_f16_to_f32")
     return y
 
@@ -525,6 +526,35 @@ def cfg_euler_step_(latents, noise_pred, sigma, sigma_next, gmin, gmax):
     L.check(lib.mofa_cfg_euler_step(L.ptr(latents), L.ptr(noise_pred), T, h * w, _ld(noise_pred), float(sigma),
                                     float(sigma_next), float(gmin), float(gmax), L.stream_ptr()), "mofa_cfg_euler_step")
     return latents
+
+
+STEP_SCALARS = 8
+
+
+def prepare_model_input_dev(latents, image_latents, out, scal):
+    """scal: fp32 [STEP_SCALARS] on the device (a row of the per-clip step table, or the graph's `cur` row)"""
+    lib = L.load()
+    T, four, h, w = latents.shape
+    _chk(scal, F32)
+    L.check(lib.mofa_prepare_model_input_dev(L.ptr(latents), L.ptr(image_latents), L.ptr(out), T, h * w, _ld(out), L.ptr(scal),
+                                             L.stream_ptr()), "mofa_prepare_model_input_dev")
+    return out
+
+
+def cfg_euler_step_dev_(latents, noise_pred, scal, gmin, gmax):
+    lib = L.load()
+    T, four, h, w = latents.shape
+    _chk(scal, F32)
+    L.check(lib.mofa_cfg_euler_step_dev(L.ptr(latents), L.ptr(noise_pred), T, h * w, _ld(noise_pred), L.ptr(scal), float(gmin),
+                                        float(gmax), L.stream_ptr()), "mofa_cfg_euler_step_dev")
+    return latents
+
+
+def step_select(table, counter, cur):
+    lib = L.load()
+    _chk(table, F32); _chk(cur, F32)
+    assert counter.dtype == torch.int32 and table.is_contiguous() and table.shape[1] == STEP_SCALARS
+    L.check(lib.mofa_step_select(L.ptr(table), L.ptr(counter), L.ptr(cur), table.shape[0], L.stream_ptr()), "mofa_step_select")
 
 
 # ---- output stage (SURVEY N4) ---------------------------------------------------------------------------

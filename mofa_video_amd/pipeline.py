@@ -35,6 +35,7 @@ Reference quirks kept: ``added_time_ids`` is always [6, 128, 0.02] (pipeline.py:
 seed does not reproduce the reference's fp16 CUDA draws -- pass ``latents=`` for reproducibility across implementations;
 (3) the scheduler's unused per-step randn draw is not made (no effect on results).
 """
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Union
 
@@ -54,6 +55,7 @@ class FlowControlNetPipelineOutput:
 
 
 MAX_TEMPORAL_FRAMES = 32        # mofa_attn_temporal_f16 holds one clip's keys in a wave: T <= 32
+GRAPH_STEPS_DEFAULT = os.environ.get("MOFA_GRAPH_STEPS", "0") == "1"
 
 
 class _Shard:
@@ -87,7 +89,12 @@ class FlowControlNetPipeline:
         self.round_latents_to_fp16 = round_latents_to_fp16
         self.overlap_adapter = True          # adapter trunk(s) || UNet encoder on two HIP streams (see _denoise_forward)
         self.split_decoder = True            # ... and the UNet decoder's two CFG halves on the same two streams
+        # capture ONE denoise step per clip in a hipGraph and replay it for the remaining steps (no host scalar enters a step:
+        # the scheduler's numbers come from a device table, _clip_loop).  Off for a rank that exchanges data inside a step (the
+        # gloo / virtual-rank transports are host side), with a step callback, and while launches are being timed.
+        self.graph_steps = GRAPH_STEPS_DEFAULT
         self._adapter_stream = None
+        self._loop_stream = None
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, unet=None, controlnet=None, device="cuda", variant=None,
@@ -129,7 +136,7 @@ class FlowControlNetPipeline:
         def trunks():
             res = []
             for net, ctx, cond, scale in adapters:
-                net.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=ctx, half=half, par=fpar)
+                net.make_ctx(t, emb, added_time_ids, Bl, Tl, base=ctx, half=half, par=fpar)
                 res.append(net.forward_tokens(x_loc, ctx, h, w, cond, scale))
             down, mid = res[0]
             if len(res) == 2:
@@ -138,7 +145,7 @@ class FlowControlNetPipeline:
 
         if not self.overlap_adapter or (fpar is not None and not fpar.two_streams):
             down, mid = trunks()
-            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+            unet.make_ctx(t, emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
             return unet.forward_tokens(x_loc, c_un, h, w, down, mid)
         if fpar is not None:
             return self._denoise_forward_sharded(trunks, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, c_un)
@@ -149,7 +156,7 @@ class FlowControlNetPipeline:
         side.wait_stream(cur)                                   # the model input (and everything before it) is ready
         with torch.cuda.stream(side):
             down, mid = trunks()
-        unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+        unet.make_ctx(t, emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
         enc = unet.encode_tokens(x_loc, c_un, h, w)
         cur.wait_stream(side)
         for r in list(down) + [mid]:                            # allocated on the side stream, consumed (and freed) on this one
@@ -168,7 +175,7 @@ class FlowControlNetPipeline:
         for hf, st in enumerate((cur, side)):
             with torch.cuda.stream(st):
                 ch = c_un.halves[hf]
-                unet.make_ctx(float(t), emb, added_time_ids, 1, Tl, base=ch, half=hf, par=None)
+                unet.make_ctx(t[hf:hf + 1] if torch.is_tensor(t) else t, emb, added_time_ids, 1, Tl, base=ch, half=hf, par=None)
 
                 def rows_of(tt, hf=hf):
                     n = tt.shape[0] // 2
@@ -210,7 +217,7 @@ class FlowControlNetPipeline:
         th.start()
         try:
             fpar.bind(tok, 1)
-            unet.make_ctx(float(t), emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
+            unet.make_ctx(t, emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
             enc = unet.encode_tokens(x_loc, c_un, h, w)
         finally:
             fpar.unbind()
@@ -297,6 +304,70 @@ class FlowControlNetPipeline:
             return lat
         return ops.cast_f16_to_f32(ops.cast_f32_to_f16(lat.contiguous())).reshape(lat.shape)
 
+    def _clip_loop(self, lat, il, emb, added_time_ids, adapters, c_un, masks, sh, h, w, g0, g1, callback):
+        """The denoise loop of one clip (pipeline.py:447-511) on this rank's CFG half / frames: ``lat`` fp32 [Tl,4,h,w] is stepped
+        in place through every timestep of the scheduler and returned.
+
+        Everything a step takes from the scheduler (sigma, sigma_next, the network's timestep, 1 / sqrt(sigma^2 + 1)) is uploaded
+        ONCE per clip as a device table (scheduler.step_table) and the kernels read their row of it: no host scalar, no H2D copy
+        inside a step.  That makes a step capturable: with ``graph_steps`` the first step runs eagerly (allocations, one-time
+        kernel set-up, per-clip caches), the second is captured in a hipGraph on the loop's own stream -- its first node copies
+        row ``counter`` of the table into a fixed ``cur`` row and increments the counter, every other node reads ``cur`` -- and
+        steps 1 .. n-1 are replays: the host issues one graph launch per step instead of ~1 400 kernel launches."""
+        sch, dev, unet = self.scheduler, self.device, self.unet
+        Tl, Bl, half, fpar = sh.Tl, sh.Bl, sh.half, sh.fpar
+        rows = Tl * h * w
+        in_ld = max([unet.in_ld] + [a[0].in_ld for a in adapters])
+        x_in = torch.zeros((2 * rows, in_ld), dtype=torch.float16, device=dev)
+        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
+        timesteps = sch.timesteps
+        n = len(timesteps)
+        self._num_timesteps = n
+        tab = torch.from_numpy(sch.step_table()).to(dev)
+
+        def step(scal):
+            ops.prepare_model_input_dev(lat, il, x_in, scal)
+            noise = self._denoise_forward(x_loc, scal[2:2 + Bl], emb, added_time_ids, Bl, Tl, half, fpar, h, w, adapters, c_un, masks)
+            if Bl == 1:
+                noise = sh.par.gather_cfg(noise)                          # both halves of this frame shard
+            ops.cfg_euler_step_dev_(lat, noise, scal, g0, g1)
+            if self.round_latents_to_fp16:
+                ops.cast_f16_to_f32(ops.cast_f32_to_f16(lat), out=lat)
+
+        if not (self.graph_steps and callback is None and sh.par is None and ops.TIMER is None and n >= 3):
+            for i, t in enumerate(timesteps):
+                step(tab[i])
+                if callback is not None:
+                    new = self._callback(callback, i, t, lat, (1, Tl, 4, h, w))
+                    if new is not lat:
+                        lat.copy_(new)
+            return lat
+        caller = torch.cuda.current_stream(dev)
+        if self._loop_stream is None:
+            self._loop_stream = torch.cuda.Stream(device=dev)
+        gs = self._loop_stream
+        gs.wait_stream(caller)
+        counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        cur = torch.empty(ops.STEP_SCALARS, dtype=torch.float32, device=dev)
+
+        def body():
+            ops.step_select(tab, counter, cur)
+            step(cur)
+        with torch.cuda.stream(gs):
+            body()                                                        # step 0, eager
+            graph = torch.cuda.CUDAGraph()
+            graph.capture_begin()
+            try:
+                body()                                                    # (recorded, not executed)
+            finally:
+                graph.capture_end()
+            for _ in range(1, n):
+                graph.replay()
+        caller.wait_stream(gs)
+        lat.record_stream(gs)
+        self._last_graph = graph                                          # keeps the graph's memory pool until the next clip
+        return lat
+
     def _callback(self, cb, i, t, lat, shape):
         """callback_on_step_end(self, i, t, {"latents": ...}) may return replacement latents (pipeline.py:503-508)"""
         if cb is None:
@@ -378,20 +449,8 @@ class FlowControlNetPipeline:
         g0, g1 = min_guidance_scale + gspan * f0, min_guidance_scale + gspan * (f1 - 1)
 
         c_cn, c_un = Ctx(Bl, Tl), Ctx(Bl, Tl)                             # hold the per-clip invariant caches
-        rows = Tl * h * w
-        x_in = torch.zeros((2 * rows, max(unet.in_ld, cn.in_ld)), dtype=torch.float16, device=dev)
-        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
-        self._num_timesteps = len(timesteps)
-        for i, t in enumerate(timesteps):                                 # :447-511
-            sigma, sigma_next = sch.sigma_pair(i)
-            ops.prepare_model_input(lat, il, x_in, sigma)
-            noise = self._denoise_forward(x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w,
-                                          [(cn, c_cn, warped, controlnet_cond_scale)], c_un)
-            if Bl == 1:
-                noise = sh.par.gather_cfg(noise)                          # both halves of this frame shard
-            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
-            lat = self._round(lat)
-            lat = self._callback(callback_on_step_end, i, t, lat, (1, Tl, 4, h, w))
+        lat = self._clip_loop(lat, il, emb, added_time_ids, [(cn, c_cn, warped, controlnet_cond_scale)], c_un, None, sh, h, w,
+                              g0, g1, callback_on_step_end)                # :447-511
 
         if fpar is not None:                                              # reassemble the clip's latents on every rank
             lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
@@ -464,20 +523,8 @@ class HybridFlowControlNetPipeline(FlowControlNetPipeline):
         masks = _resized_masks(mask, height, width, h, w, dev)
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
         c_f, c_d, c_u = Ctx(Bl, Tl), Ctx(Bl, Tl), Ctx(Bl, Tl)
-        rows = Tl * h * w
-        x_in = torch.zeros((2 * rows, unet.in_ld), dtype=torch.float16, device=dev)
-        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
-        self._num_timesteps = len(timesteps)
-        for i, t in enumerate(timesteps):
-            sigma, sigma_next = sch.sigma_pair(i)
-            ops.prepare_model_input(lat, il, x_in, sigma)
-            noise = self._denoise_forward(x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w,
-                                          [(face, c_f, cf, ctrl_scale_ldmk), (drag, c_d, cd, ctrl_scale_traj)], c_u, masks)
-            if Bl == 1:
-                noise = sh.par.gather_cfg(noise)
-            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
-            lat = self._round(lat)
-            lat = self._callback(callback_on_step_end, i, t, lat, (1, Tl, 4, h, w))
+        lat = self._clip_loop(lat, il, emb, added_time_ids, [(face, c_f, cf, ctrl_scale_ldmk), (drag, c_d, cd, ctrl_scale_traj)],
+                              c_u, masks, sh, h, w, g0, g1, callback_on_step_end)
         if fpar is not None:
             lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
         frames = self._decode(lat.reshape(1, T, 4, h, w), T, decode_chunk_size, output_type, sh)
@@ -542,20 +589,8 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         g0, g1 = gmin + gspan * f0, gmin + gspan * (f1 - 1)
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
         c_f, c_d, c_u = Ctx(Bl, Tl), Ctx(Bl, Tl), Ctx(Bl, Tl)
-        rows = Tl * h * w
-        x_in = torch.zeros((2 * rows, unet.in_ld), dtype=torch.float16, device=dev)
-        x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
-        self._num_timesteps = len(timesteps)
-        for i, t in enumerate(timesteps):
-            sigma, sigma_next = sch.sigma_pair(i)
-            ops.prepare_model_input(lat, il, x_in, sigma)
-            adapters = [(cn, c_f, cf, cn_scale)] + ([(drag, c_d, cd, traj_scale)] if hybrid else [])
-            noise = self._denoise_forward(x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, adapters, c_u, masks)
-            if Bl == 1:
-                noise = sh.par.gather_cfg(noise)
-            ops.cfg_euler_step_(lat, noise, sigma, sigma_next, g0, g1)
-            lat = self._round(lat)
-            lat = self._callback(callback, i, t, lat, (1, Tl, 4, h, w))
+        adapters = [(cn, c_f, cf, cn_scale)] + ([(drag, c_d, cd, traj_scale)] if hybrid else [])
+        lat = self._clip_loop(lat, il, emb, added_time_ids, adapters, c_u, masks, sh, h, w, g0, g1, callback)
         if fpar is not None:
             lat = fpar.gather_frames(lat.reshape(Tl, 4 * h * w), 1).reshape(T, 4, h, w)
         return lat

@@ -87,5 +87,17 @@ class EulerDiscreteScheduler:
     def step_index(self):
         return self._step_index
 
+    def step_table(self):
+        """fp32 [num_inference_steps, 8] rows {sigma, sigma_next, timestep, timestep, 1 / sqrt(sigma^2 + 1), 0, 0, 0}: everything
+        a denoise step takes from the scheduler (scale_model_input :284-285, step :504-520, the network's timestep), uploaded
+        once per clip (include/mofa_hip.h, MOFA_STEP_SCALARS) -- float32 arithmetic as the host-scalar entry points do it"""
+        n = len(self.timesteps)
+        tab = np.zeros((n, 8), dtype=np.float32)
+        sig = self.sigmas.astype(np.float32)
+        tab[:, 0], tab[:, 1] = sig[:n], sig[1:n + 1]
+        tab[:, 2] = tab[:, 3] = self.timesteps
+        tab[:, 4] = np.float32(1.0) / np.sqrt(sig[:n] * sig[:n] + np.float32(1.0))
+        return tab
+
     def sigma_pair(self, i):
         return float(self.sigmas[i]), float(self.sigmas[i + 1])

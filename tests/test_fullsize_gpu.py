@@ -66,6 +66,24 @@ def test_fullsize_two_streams_equal_single_stream(full):
     assert e < 2e-3, e
 
 
+def test_fullsize_graph_replayed_steps_bit_identical(full):
+    """pipeline.graph_steps: step 0 eager, step 1 captured in a hipGraph (first node: row `counter` of the device step table ->
+    `cur`), steps 1 .. n-1 replayed -- same kernels, same arguments, same two-stream order: the same bits as the eager loop"""
+    from mofa_video_amd.pipeline import FlowControlNetPipeline
+    pipe, inp, run = full
+
+    def run4(graph):
+        p = FlowControlNetPipeline(vae=pipe.vae, unet=pipe.unet, controlnet=pipe.controlnet, scheduler=type(pipe.scheduler)())
+        p.graph_steps = graph
+        return p(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], height=bench.H, width=bench.W,
+                 num_frames=bench.T, num_inference_steps=4, decode_chunk_size=bench.CHUNK, latents=inp["latents"],
+                 output_type="latent", image_embeddings=inp["image_embeddings"], image_latents=inp["image_latents"]).frames
+    a, b, c = run4(False), run4(True), run4(True)
+    assert torch.isfinite(a).all()
+    assert torch.equal(b, c)
+    assert torch.equal(a, b)
+
+
 def test_fullsize_zero_adapter_scale_ignores_flow(full):
     pipe, inp, run = full
     a = run(scale=0.0)

@@ -3,7 +3,11 @@ synchronisation, so `enqueue` = what the host needs to issue N steps, `gpu` = un
 GPU the host runs far ahead; per-rank GPU time shrinks with the frame shards while the host time does not -- this is the
 strong-scaling limit to watch.
 
-    python tools/host_time.py [steps]
+    python tools/host_time.py [steps] [HxWxT] [graph]
+
+``HxWxT`` (e.g. 64x64x4) keeps every layer and launch but makes the device work negligible: the enqueue time then IS the host
+cost of a step (at full size the HIP queue fills and the host is throttled to the device's pace).  ``graph``: with
+pipeline.graph_steps (one hipGraph launch per step from the third step on).
 """
 import os
 import sys
@@ -17,10 +21,11 @@ import bench  # noqa: E402
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    if len(sys.argv) > 2:                                  # python tools/host_time.py 4 64x64x4 : same layers, negligible device work
+    if len(sys.argv) > 2 and "x" in sys.argv[2]:           # python tools/host_time.py 4 64x64x4 : same layers, negligible device work
         bench.H, bench.W, bench.T = (int(v) for v in sys.argv[2].split("x"))
     dev = torch.device("cuda", 0)
     pipe = bench.build_pipeline(dev)
+    pipe.graph_steps = "graph" in sys.argv[2:]
     inp = bench.synthetic_inputs(dev)
 
     def run(n):
@@ -30,7 +35,8 @@ def main():
     run(1)
     torch.cuda.synchronize()
     res = {}
-    for n in (1, 1 + steps):
+    base = 3 if pipe.graph_steps else 1                    # (graph mode: step 0 eager, step 1 = the capture, replays from then on)
+    for n in (base, base + steps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(n)
@@ -38,10 +44,11 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         res[n] = (t1 - t0, t2 - t0)
-    enq = (res[1 + steps][0] - res[1][0]) / steps
-    gpu = (res[1 + steps][1] - res[1][1]) / steps
-    print(f"per denoise step ({bench.T} f {bench.H}x{bench.W}, CFG 2): host enqueue {enq * 1e3:.1f} ms, device {gpu * 1e3:.1f} ms "
-          f"(host / device = {enq / gpu:.2f}); per-clip prologue (1 step run): enqueue {res[1][0] * 1e3:.0f} ms, total {res[1][1] * 1e3:.0f} ms")
+    enq = (res[base + steps][0] - res[base][0]) / steps
+    gpu = (res[base + steps][1] - res[base][1]) / steps
+    mode = "hipGraph replay" if pipe.graph_steps else "eager launches"
+    print(f"per denoise step ({bench.T} f {bench.H}x{bench.W}, CFG 2, {mode}): host enqueue {enq * 1e3:.1f} ms, device {gpu * 1e3:.1f} ms "
+          f"(host / device = {enq / gpu:.2f}); {base}-step run: enqueue {res[base][0] * 1e3:.0f} ms, total {res[base][1] * 1e3:.0f} ms")
 
 
 if __name__ == "__main__":
