@@ -355,14 +355,26 @@ def main():
     cfg = args.config
     pipe = build_config_pipeline(dev, cfg, seed=0)
     mode = args.mode if world > 1 else "single"
-    comm_paths = None
+    comm_paths = window_plan = None
     if mode == "shard":
         # every rank must see the same clip; partition = mofa_video_amd/parallel.py.  A failure here is an error: a
         # strong-scaling request must never silently turn into independent replicas
-        from mofa_video_amd.parallel import FrameParallel, Layout, TorchComm, WindowParallel
-        if cfg == 5:                                        # long video: the windows of a step are dealt to the ranks
-            comm = TorchComm(lambda r: Layout(1, 0, T))
-            pipe.parallel = WindowParallel(comm, rank, world)
+        from mofa_video_amd.parallel import (FrameParallel, GroupedWindowParallel, Layout, TorchComm, WindowParallel, plan_windows,
+                                             window_layout_costs)
+        if cfg == 5:                                        # long video: the layout the cost table picks for (windows, ranks)
+            from mofa_video_amd.pipeline import window_views
+            nwin = len(set(window_views(LONG_FRAMES, T, T // 2)))
+            plan = plan_windows(nwin, world)
+            window_plan = dict(windows=nwin, chosen=plan, costs=[(round(c, 3), n, G, g) for c, n, G, g in window_layout_costs(nwin, world)])
+            if plan[0] == "window":
+                comm = TorchComm(lambda r: Layout(1, 0, T))
+                pipe.parallel = WindowParallel(comm, rank, world)
+            elif plan[0] == "frame":
+                comm = TorchComm(lambda r: Layout(world, r, T))
+                pipe.parallel = FrameParallel(Layout(world, rank, T), comm)
+            else:
+                comm = TorchComm(GroupedWindowParallel.layout_of_rank(world, plan[2], T))
+                pipe.parallel = GroupedWindowParallel(comm, rank, world, plan[2], T)
             comm.all_gather_world(torch.ones(4, device=dev))
         else:
             if world % 2 != 0:
@@ -475,8 +487,8 @@ def main():
         nfr = LONG_FRAMES if cfg == 5 else T
         value = nfr * clips / dt
         par_desc = {"single": "1 GPU", "replicas": f"{world} independent clips, one per GPU, no data-path collective",
-                    "shard": (f"one clip over {world} GPUs: the distinct windows of a step dealt round-robin to the ranks, one "
-                              "all-gather of the stepped window latents per round; VAE chunks round-robin" if cfg == 5 else
+                    "shard": (f"one clip over {world} GPUs, layout from parallel.window_layout_costs: {window_plan}; one all-gather of "
+                              "the stepped window latents per round; VAE chunks dealt over all ranks" if cfg == 5 else
                               f"one clip over {world} GPUs: 2-way CFG x {max(world // 2, 1)}-way frame shards; RCCL "
                               "all-reduce (temporal GroupNorm sums), halo p2p (temporal convs), all-gather (temporal "
                               "attention K|V, CFG pair, final latents); VAE chunks round-robin")}[mode]

@@ -25,12 +25,14 @@ def _hipcc():
     return hipcc if os.path.exists(hipcc) else "hipcc"
 
 
-def build(force=False, verbose=False, probe=False):
-    objdir = os.path.join(HERE, "build", "probe" if probe else "lib")
+def build(force=False, verbose=False, probe=False, variant=None, defines=()):
+    """variant / defines: an A/B build ``tools/libmofa_hip_<variant>.so`` with extra -D flags (bench.py / the tools take it with
+    ``--lib``); experiments only, the product library is always built without them"""
+    objdir = os.path.join(HERE, "build", variant or ("probe" if probe else "lib"))
     os.makedirs(objdir, exist_ok=True)
-    lib = PROBE_LIB if probe else LIB
+    lib = os.path.join(HERE, "..", "tools", f"libmofa_hip_{variant}.so") if variant else (PROBE_LIB if probe else LIB)
     hdr_t = max(os.path.getmtime(h) for h in HEADERS if os.path.exists(h))
-    flags = FLAGS + (["-DMOFA_PROBE"] if probe else [])
+    flags = FLAGS + (["-DMOFA_PROBE"] if probe else []) + [f"-D{d}" for d in defines]
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
@@ -53,4 +55,6 @@ def build(force=False, verbose=False, probe=False):
 
 if __name__ == "__main__":
     import sys
-    print(build(force="--incremental" not in sys.argv, verbose=True, probe="--probe" in sys.argv))
+    var = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--incremental" not in sys.argv, verbose=True, probe="--probe" in sys.argv, variant=var,
+                defines=[a[2:] for a in sys.argv if a.startswith("-D")]))

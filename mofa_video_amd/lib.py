@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmofa_hip.so")
+# (MOFA_HIP_LIB: another BUILD of the same library for same-box A/B runs of the test suite and the tools -- never a fallback)
+LIB_PATH = os.environ.get("MOFA_HIP_LIB") or os.path.join(_HERE, "libmofa_hip.so")
 
 MODE_PLAIN, MODE_CONV3X3, MODE_CONVT3 = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GEGLU_PAIR, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4

@@ -47,9 +47,11 @@ def split_frames(T, n):
 
 
 class Layout:
-    def __init__(self, world, rank, T, cfg_ranks=None):
+    def __init__(self, world, rank, T, cfg_ranks=None, base=0):
         """cfg_ranks: None = 2 whenever world >= 2 (the product layout).  1 = frames only (both CFG halves on every
-        rank) -- used by the exchange-primitive tests to shard frames over 2 ranks; the pipelines use the default."""
+        rank) -- used by the exchange-primitive tests to shard frames over 2 ranks; the pipelines use the default.
+        base: this layout covers the GLOBAL ranks [base, base + world) (one group of GroupedWindowParallel); ``rank`` is the
+        position inside it, the group lists hold global ranks."""
         if cfg_ranks is None:
             assert world >= 1 and (world == 1 or world % 2 == 0), "1 or an even number of ranks"
             cfg_ranks = 2 if world >= 2 else 1
@@ -65,8 +67,9 @@ class Layout:
         self.T_loc = self.f1 - self.f0
         self.T_max = self.bounds[0][1] - self.bounds[0][0]
         h = self.half or 0
-        self.frame_group = [h * self.frame_ranks + s for s in range(self.frame_ranks)]
-        self.pair_group = [self.shard, self.frame_ranks + self.shard] if self.cfg_ranks == 2 else [rank]
+        self.base = base
+        self.frame_group = [base + h * self.frame_ranks + s for s in range(self.frame_ranks)]
+        self.pair_group = [base + self.shard, base + self.frame_ranks + self.shard] if self.cfg_ranks == 2 else [base + rank]
         self.prev_rank = self.frame_group[self.shard - 1] if self.shard > 0 else None
         self.next_rank = self.frame_group[self.shard + 1] if self.shard + 1 < self.frame_ranks else None
         self.B_loc = 1 if self.cfg_ranks == 2 else 2
@@ -274,7 +277,7 @@ class TurnToken:
     program alone (both threads run the same code on every rank), never on host timing, so all ranks issue the same sequence
     on every communicator: the condition under which RCCL cannot deadlock.  ``log`` records (role, tag) per group (tests)."""
 
-    def __init__(self, first=0, timeout=600.0, enforce=True):
+    def __init__(self, first=0, timeout=180.0, enforce=True):
         self.cv = threading.Condition()
         self.holder, self.active, self.timeout, self.enforce = first, [True, True], timeout, enforce
         self.log = []
@@ -493,6 +496,37 @@ class FrameParallel:
 
 
 # ---------------------------------------------------------------------------------------------------------
+class GroupedWindowParallel:
+    """Long video on more ranks than one window per rank can use: G = world / g groups of g ranks.  The distinct windows of a
+    step are dealt round-robin to the GROUPS (as WindowParallel deals them to ranks) and every group runs its window
+    frame-parallel (2-way CFG x g/2 frame shards inside the group, ``self.frame``); after a round ONE all-gather over all ranks
+    hands every rank every stepped window (the g ranks of a group hold identical copies; entry 0 of each group is used).
+    ``window_layout_costs`` says when this beats the two plain layouts (e.g. 4 windows on 8 ranks: 4 x 2)."""
+
+    def __init__(self, comm, rank, world, ranks_per_group, window_size):
+        g = ranks_per_group
+        assert world % g == 0 and g >= 2 and g % 2 == 0
+        self.comm, self.rank, self.world, self.g = comm, rank, world, g
+        self.groups, self.slot = world // g, rank // g
+        self.frame = FrameParallel(Layout(g, rank % g, window_size, base=self.slot * g), comm)
+
+    @staticmethod
+    def layout_of_rank(world, ranks_per_group, window_size):
+        """the ``layout_of_rank`` argument of TorchComm for this arrangement"""
+        g = ranks_per_group
+        return lambda r: Layout(g, r % g, window_size, base=(r // g) * g)
+
+    def rounds(self, keys):
+        out = []
+        for j in range(0, len(keys), self.groups):
+            chunk = list(keys[j:j + self.groups])
+            out.append(chunk + [None] * (self.groups - len(chunk)))
+        return out
+
+    def gather(self, t):
+        return self.comm.all_gather_world(t)[::self.g]
+
+
 class WindowParallel:
     """Long-video (Keypoint window loop) sharding: the DISTINCT temporal windows of one denoise step are independent
     (MOFA-Video-Keypoint/pipeline/svdxt_pipeline_ctrlnet_loop.py:470-511), so they are dealt round-robin to the ranks;
@@ -501,6 +535,7 @@ class WindowParallel:
 
     def __init__(self, comm, rank, world):
         self.comm, self.rank, self.world = comm, rank, world
+        self.slot = rank                     # position in a round (GroupedWindowParallel: the group)
 
     def rounds(self, keys):
         """keys: the distinct windows in view order -> list of rounds, each a list of ``world`` keys (None = idle slot)"""
@@ -512,3 +547,46 @@ class WindowParallel:
 
     def gather(self, t):
         return self.comm.all_gather_world(t)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Which layout for a long video (Keypoint window loop) on R ranks?  A pure cost table, no device work.
+# ---------------------------------------------------------------------------------------------------------
+# time of ONE window step on g ranks (2-way CFG x g/2 frame shards) relative to one rank.  ASSUMED until an 8-GPU node has
+# measured them (none has: every SCALE record of this build is a skipped one): g = 2 loses only the CFG pair exchange and the
+# halved tile counts (the single-GPU two-half probe: 252-253 ms against 247.8 for the whole batch, profiles/r03c_stream_variants_probe.log);
+# g = 4 / 8 add the per-rank shapes' lower MFMA rate (profiles/r04_shard_shapes.log) and the exchange groups of the temporal layers.
+WINDOW_STEP_TIME = {1: 1.0, 2: 0.53, 4: 0.29, 8: 0.17}
+
+
+def window_layout_costs(windows, ranks, step_time=None):
+    """-> list of (cost, name, groups, ranks_per_group) sorted by cost: the time of one denoise step over ``windows`` distinct
+    windows on ``ranks`` ranks, in units of one window step on one rank, for every way this package can spread them:
+
+      "window"   WindowParallel: one window per rank and round, ceil(windows / ranks) rounds (ranks beyond the windows idle);
+      "frame"    FrameParallel with a Layout of window_size frames: every window on ALL ranks, one after the other;
+      "groups"   G groups of g = ranks / G ranks (g even): the windows dealt to the groups round-robin, every group runs its
+                 window frame-parallel -- WindowParallel over group leaders composed with FrameParallel inside a group.
+
+    With 7 windows on 8 ranks no split beats "window" (cost 1.0, one rank idle): a window finishes sooner only on >= 2 ranks,
+    seven windows on >= 2 ranks each need 14 rank slots, i.e. two rounds of >= 0.53 each.  The eighth rank's share of the work is
+    the VAE decode (13 chunks dealt over all 8 ranks after the loop)."""
+    st = dict(WINDOW_STEP_TIME)
+    st.update(step_time or {})
+    out = []
+    out.append((float(-(-windows // ranks)) * st[1], "window", ranks, 1))
+    if ranks in st and ranks >= 2:
+        out.append((windows * st[ranks], "frame", 1, ranks))
+    g = 2
+    while g < ranks:
+        if ranks % g == 0 and g in st:
+            G = ranks // g
+            out.append((float(-(-windows // G)) * st[g], "groups", G, g))
+        g *= 2
+    return sorted(out, key=lambda c: (c[0], {"window": 0, "frame": 1, "groups": 2}[c[1]]))
+
+
+def plan_windows(windows, ranks, step_time=None):
+    """the cheapest layout of ``window_layout_costs`` as (name, groups, ranks_per_group)"""
+    c = window_layout_costs(windows, ranks, step_time)[0]
+    return c[1], c[2], c[3]

@@ -202,10 +202,11 @@ class FlowControlNetPipeline:
         side.wait_stream(cur)
         tok = TurnToken(first=0)
         box = {}
+        dev_index = torch.cuda.current_device()                 # (self.device may carry no index; the new thread needs one)
 
         def trunk_thread():
             try:
-                torch.cuda.set_device(dev)
+                torch.cuda.set_device(dev_index)
                 fpar.bind(tok, 0)
                 with torch.no_grad(), torch.cuda.stream(side):
                     box["res"] = trunks()
@@ -213,6 +214,7 @@ class FlowControlNetPipeline:
                 box["err"] = e
             finally:
                 fpar.unbind()
+                tok.finish(0)                                   # whatever happened: the encoder must never wait for a dead trunk
         th = threading.Thread(target=trunk_thread, name="mofa-adapter-trunk")
         th.start()
         try:
@@ -221,6 +223,7 @@ class FlowControlNetPipeline:
             enc = unet.encode_tokens(x_loc, c_un, h, w)
         finally:
             fpar.unbind()
+            tok.finish(1)
             th.join()
         if "err" in box:
             raise box["err"]
@@ -627,9 +630,10 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         flow = controlnet_flow.to(dev, torch.float32)
         dflow = drag_flow.to(dev, torch.float32) if hybrid else None
         views = window_views(N, Tw, stride)
-        from .parallel import FrameParallel
-        framepar = self.parallel if isinstance(self.parallel, FrameParallel) else None
-        if framepar is not None and len(set(views)) == 1 and N == Tw:
+        from .parallel import FrameParallel, GroupedWindowParallel
+        grouped = self.parallel if isinstance(self.parallel, GroupedWindowParallel) else None
+        framepar = self.parallel if isinstance(self.parallel, FrameParallel) else (grouped.frame if grouped is not None else None)
+        if framepar is not None and grouped is None and len(set(views)) == 1 and N == Tw:
             # ONE window that is the whole clip (N == window_size: every view is frames 1 .. N-1 behind frame 0): the loop
             # degenerates to the plain denoise loop -- value = k * stepped window, count = k -- so the clip is frame-sharded
             # exactly like FlowControlNetPipeline / HybridFlowControlNetPipeline (2-way CFG x frame shards) and the latents
@@ -642,13 +646,14 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
             if not return_dict:
                 return frames, controlnet_flow
             return FlowControlNetPipelineOutput(frames=frames, controlnet_flow=controlnet_flow)
-        # Several windows, three ways to spread them (self.parallel):
+        # Several windows, four ways to spread them (self.parallel; parallel.window_layout_costs prices them):
         #   None            every window on this GPU, one after the other;
         #   WindowParallel  the distinct windows of a step dealt to the ranks, one all-gather per round;
         #   FrameParallel   (Layout of window_size frames) every window on ALL ranks, 2-way CFG x frame shards inside the
         #                   window, the stepped window gathered before the overlap average -- the layout for more ranks than
-        #                   windows (on 8 ranks and 7 windows WindowParallel's single round is the faster of the two).
-        # In all three every rank holds all N latent frames and applies the same overlap average in view order.
+        #                   windows (on 8 ranks and 7 windows WindowParallel's single round is the faster of the two);
+        #   GroupedWindowParallel  G groups of g ranks: windows dealt to the groups, frame-parallel inside a group.
+        # In all of them every rank holds all N latent frames and applies the same overlap average in view order.
         sh_w = _Shard(framepar, Tw)
         f0, f1, Tl, Bl, half, fpar = sh_w.f0, sh_w.f1, sh_w.Tl, sh_w.Bl, sh_w.half, sh_w.fpar
         # adapter state per DISTINCT window is timestep-invariant: computed once per clip (the reference recomputes it
@@ -665,11 +670,12 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
         added_time_ids = torch.tensor([[6.0, 128.0, 0.02]] * 2, dtype=torch.float32, device=dev)
         ctxs = {v: (Ctx(Bl, Tl), Ctx(Bl, Tl), Ctx(Bl, Tl)) for v in conds}
         distinct = list(conds)                                                     # distinct windows, in view order
-        wpar = self.parallel if framepar is None else None                         # parallel.WindowParallel or None
-        if framepar is not None:
-            world, rank = sh_w.world, sh_w.rank
+        wpar = grouped if grouped is not None else (self.parallel if framepar is None else None)   # deals windows, or None
+        if wpar is not None:
+            world, rank = wpar.world, wpar.rank                                    # (global: VAE chunks go to all ranks)
         else:
-            world, rank = (wpar.world, wpar.rank) if wpar is not None else (1, 0)
+            world, rank = (sh_w.world, sh_w.rank) if framepar is not None else (1, 0)
+        nslots, slot = (len(wpar.rounds(list(conds))[0]), wpar.slot) if wpar is not None else (1, 0)
         rows = Tl * h * w
         x_in = torch.zeros((2 * rows, unet.in_ld), dtype=torch.float16, device=dev)
         x_loc = x_in if Bl == 2 else x_in[half * rows:(half + 1) * rows]
@@ -738,7 +744,7 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
                 if wpar is None:
                     done[rnd[0]] = step_window(*rnd[0])
                 else:                                             # window-parallel: one window per rank and round
-                    mine = rnd[rank]
+                    mine = rnd[slot]
                     lw = step_window(*mine) if mine is not None else torch.zeros((Tw,) + tuple(lat.shape[1:]),
                                                                                 dtype=lat.dtype, device=dev)
                     for key, got in zip(rnd, wpar.gather(lw)):
@@ -758,7 +764,7 @@ class KeypointFlowControlNetPipeline(FlowControlNetPipeline):
                 finalize(range(frontier, newf))
                 frontier = newf
                 ready = [ci for ci in range(nchunks) if ci not in owner and min((ci + 1) * decode_chunk_size, N) <= frontier]
-                busy_next = [r for r in range(world) if wpar is None or rounds[ri + 1][r] is not None]
+                busy_next = [r for r in range(world) if wpar is None or rounds[ri + 1][r * nslots // world] is not None]
                 for ci, r in _deal_ready_chunks(ready, world, busy_next):
                     owner[ci] = r
                 mine = [ci for ci in ready if owner.get(ci) == rank]

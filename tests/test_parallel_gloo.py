@@ -302,3 +302,24 @@ def test_turn_token_times_out_instead_of_hanging():
         tok.acquire(1)                       # role 0 holds the token and never issues anything
     tok.finish(0)
     tok.acquire(1)                           # ... and a finished partner hands it over for good
+
+
+def test_grouped_layout_and_window_cost_table():
+    """GroupedWindowParallel's group layouts hold GLOBAL ranks; the cost table is a pure function of (windows, ranks)"""
+    from mofa_video_amd.parallel import GroupedWindowParallel, plan_windows, window_layout_costs
+    lay = Layout(4, 1, 25, base=4)                   # second group of 4 on 8 ranks: 2-way CFG x 2 frame shards on ranks 4..7
+    assert (lay.half, lay.shard, lay.frame_group, lay.pair_group) == (0, 1, [4, 5], [5, 7])
+    assert (lay.prev_rank, lay.next_rank) == (4, None)
+    lor = GroupedWindowParallel.layout_of_rank(8, 4, 25)
+    groups = {tuple(lor(r).frame_group) for r in range(8)}
+    assert groups == {(0, 1), (2, 3), (4, 5), (6, 7)}
+    assert {tuple(lor(r).pair_group) for r in range(8)} == {(0, 2), (1, 3), (4, 6), (5, 7)}
+    # BASELINE config 5: 7 windows on 8 ranks -> one window per rank, one rank idle (any split needs two rounds)
+    assert plan_windows(7, 8) == ("window", 8, 1)
+    costs = {(n, G, g): c for c, n, G, g in window_layout_costs(7, 8)}
+    assert costs[("window", 8, 1)] == 1.0 and costs[("groups", 4, 2)] == pytest.approx(2 * 0.53)
+    assert plan_windows(4, 8) == ("groups", 4, 2)    # fewer windows than half the ranks: CFG pairs
+    assert plan_windows(1, 8) == ("frame", 1, 8) and plan_windows(2, 8)[0] == "groups"
+    assert plan_windows(15, 8) == ("window", 8, 1) and plan_windows(7, 4) == ("window", 4, 1)
+    # measured step times replace the assumed ones: with perfect 8-way scaling frame sharding wins for 7 windows
+    assert plan_windows(7, 8, {8: 0.125})[0] == "frame"

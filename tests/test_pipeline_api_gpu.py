@@ -292,3 +292,38 @@ def test_keypoint_several_windows_frame_sharded(ldmk, world):
             e = rel_l2(fr, ref_frames[0, :, s0:s0 + fr.shape[0]].permute(1, 0, 2, 3))
             assert e < 1e-2, (r, s0, e)
     assert sorted(seen) == list(range(0, N, chunk))
+
+
+@pytest.mark.parametrize("world,g", [(4, 2), (8, 4)])
+def test_keypoint_grouped_windows(ldmk, world, g):
+    """parallel.GroupedWindowParallel: world / g groups of g ranks, the windows of a step dealt to the groups, every group
+    frame-parallel on its window (g = 2: the CFG pair; g = 4: 2-way CFG x 2 frame shards under the two-thread turn token).
+    Latents as on one rank, every decode chunk from exactly one of the ``world`` ranks."""
+    from mofa_video_amd.parallel import GroupedWindowParallel, ThreadComm
+    from mofa_video_amd.pipeline import KeypointFlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    of, od, ou, hf, hd, hu, hv = ldmk
+    N, win, stride, chunk = 10, 4, 2, 2                                  # 4 distinct windows, 5 decode chunks
+    inp, lm, drag, mask = _long_inputs(N)
+
+    def run(parallel=None, output_type="latent"):
+        pipe = KeypointFlowControlNetPipeline(vae=hv, unet=hu, controlnet=hf, drag_controlnet=hd, scheduler=EulerDiscreteScheduler(),
+                                              parallel=parallel)
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=lm.to(DEV), window_size=win,
+                    stride=stride, height=H, width=W, num_frames=N, num_inference_steps=2, decode_chunk_size=chunk,
+                    latents=inp["latents"], output_type=output_type, image_embeddings=inp["image_embeddings"],
+                    image_latents=inp["image_latents"], drag_flow=drag, mask=mask, ctrl_scale_traj=0.8).frames
+    ref, ref_frames = run(), run(output_type="raw")
+    res = _run_ranks(world, lambda r, tw: run(GroupedWindowParallel(ThreadComm(tw, r), r, world, g, win)))
+    for r, o in enumerate(res):
+        e = rel_l2(o, ref)
+        print(f"keypoint loop, {world // g} groups x {g} ranks, rank {r}: latents rel-L2 vs single rank {e:.3e}")
+        assert tuple(o.shape) == tuple(ref.shape) and e < 2e-3, (r, e)
+    res = _run_ranks(world, lambda r, tw: run(GroupedWindowParallel(ThreadComm(tw, r), r, world, g, win), "raw"))
+    seen = {}
+    for r, chunks in enumerate(res):
+        for s0, fr in chunks:
+            assert s0 not in seen, (s0, r, seen)
+            seen[s0] = r
+            assert rel_l2(fr, ref_frames[0, :, s0:s0 + fr.shape[0]].permute(1, 0, 2, 3)) < 1e-2, (r, s0)
+    assert sorted(seen) == list(range(0, N, chunk)), seen

@@ -19,7 +19,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--qb", type=int, default=0, help="0 = the launcher's rule, 1 / 2 = 128- / 256-row workgroups")
+    ap.add_argument("--lib", default="", help="A/B: load this build of libmofa_hip.so instead of the in-tree one")
     args = ap.parse_args()
+    if args.lib:
+        lib.LIB_PATH = os.path.abspath(args.lib)
+        print("library:", lib.LIB_PATH)
     lib.load()
     torch.manual_seed(0)
     for (fr, heads, S, tag) in [(50, 5, 9216, "L0"), (50, 10, 2304, "L1"), (50, 5, 9216 - 40, "L0 ragged"), (4, 5, 1000, "small ragged")]:

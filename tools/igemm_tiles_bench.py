@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--tiles", default="192,256p,320p,auto")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape tags to run")
     ap.add_argument("--lib", default="", help="A/B: load this build of libmofa_hip.so instead of the in-tree one")
+    ap.add_argument("--div", type=int, default=1, help="per-rank shapes of an N-GPU run: rows / N (N = 8: one CFG half x 4 frame shards)")
     args = ap.parse_args()
     if args.lib:
         lib.LIB_PATH = os.path.abspath(args.lib)
@@ -107,6 +108,13 @@ def main():
     tot = {n: 0.0 for n, _ in tiles}
     tot_best, tot_fl = 0.0, 0.0
     for (mode, Mg, N, Cin, epi, weight, tag) in shapes:
+        if args.div > 1:
+            if mode == "gemm":
+                Mg = Mg // args.div
+            elif mode == "conv":
+                Mg = (max(Mg[0] // args.div, 1), Mg[1], Mg[2])
+            else:
+                Mg = (1, max(Mg[1] * Mg[0] // args.div, 1), Mg[2])      # (clips, frames, HW): a shard of one clip
         call, fl = make_call(mode, Mg, N, Cin, epi)
         times = {n: [] for n, _ in tiles}
         ok = {}

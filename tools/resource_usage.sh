@@ -1,5 +1,5 @@
 # usage: bash tools/resource_usage.sh mofa_video_amd/csrc/igemm8.hip   -> kernel, VGPRs, spills, scratch per kernel (gfx950)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c --cuda-device-only -Rpass-analysis=kernel-resource-usage "$1" -o /dev/null 2>&1 |
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -c --cuda-device-only -Rpass-analysis=kernel-resource-usage "$1" ${@:2} -o /dev/null 2>&1 |
   python3 -c '
 import re, sys
 name = None
