@@ -128,49 +128,9 @@ class GegluFF:
         self.w1, self.b1 = s.dev(pack_linear(w)), s.dev(f32(b))
         self.out = Linear(s.sub("net.2"))
 
-    # Row-chunked form: projection and net.2 chunk by chunk (<= CHUNK_BYTES of hidden rows each, whole 256-row tiles) so that net.2
-    # reads its operand from the 256 MB Infinity Cache instead of HBM when the 4C-wide hidden tensor of the whole batch does not
-    # fit (level 0 of the bench: 460 800 x 1280 = 1.18 GB).  Same kernels on the same tiles.  OFF by default: in isolation the
-    # level-0 feed-forward gains 6 % (1 556 -> 1 465 us, tools/ff_chunk_probe.py), in the clip it loses 0.3-0.4 % in every mode
-    # (single stream 6 430 / 6 452 -> 6 409 / 6 427 ms, two streams 6 296 / 6 308 -> 6 278 / 6 285: profiles/r03c_ff_chunking_ab.log)
-    # -- 6 300 more launches per clip, and beside other kernels the cache is not the feed-forward's alone.  Kept (and tested)
-    # for footprints where the hidden tensor must not exist as a whole; set CHUNK_ABOVE_BYTES to enable.
-    CHUNK_ABOVE_BYTES = 1 << 62
-    CHUNK_BYTES = 160 << 20
-
     def __call__(self, x, **epilogue):
-        M, hid = x.shape[0], self.w1.shape[0] // 2
-        rowvec, rv = epilogue.get("rowvec"), epilogue.get("rv", (1, 1, 1, BIG))
-        unit = 256
-        if rowvec is not None:                                   # chunks must start where the row-vector index pattern restarts
-            unit = 256 * rv[0] // math.gcd(256, rv[0]) if rv[2] == 1 else 0
-        rows = (self.CHUNK_BYTES // (hid * 2)) // unit * unit if unit else 0
-        if M * hid * 2 <= self.CHUNK_ABOVE_BYTES or rows <= 0 or rows >= M:
-            h = ops.igemm(x, self.w1, self.b1, act=L.ACT_GEGLU_PAIR)
-            return self.out(h, **epilogue)
-        # fixed-size chunks (65 536 rows = 256 row tiles = one full round of the persistent grid on the bench's level 0); a short
-        # remainder joins the last chunk instead of running as launches of its own -- on the bench 2 048 rows (one frame, 9 216
-        # rows, behind a frame-periodic row vector): 8 / 36 tiles on 256 CUs at 60-470 TF/s, 27 ms per clip
-        bounds = list(range(0, M, rows)) + [M]
-        if len(bounds) > 2 and bounds[-1] - bounds[-2] < rows // 4:
-            del bounds[-2]
-        out = torch.empty((M, self.out.n_real), dtype=torch.float16, device=x.device)
-        h = torch.empty((max(b - a for a, b in zip(bounds, bounds[1:])), hid), dtype=torch.float16, device=x.device)
-        for m0, m1 in zip(bounds, bounds[1:]):
-            hh = ops.igemm(x[m0:m1], self.w1, self.b1, act=L.ACT_GEGLU_PAIR, out=h[:m1 - m0])
-            kw = {k: (v[m0:m1] if k in ("r1", "r2") and v is not None else v) for k, v in epilogue.items()}
-            if rowvec is not None:
-                # idx(m0 + m) = (idx(m0) + idx(m)) % mod_out when m0 is a multiple of rv_div (and rv_mod_in == 1): the chunk
-                # reads a table rotated / offset by idx(m0)
-                i0 = (m0 // rv[0]) * rv[1]
-                if rv[3] >= BIG:
-                    kw["rowvec"] = rowvec[i0:]
-                else:
-                    assert rowvec.shape[0] == rv[3]
-                    i0 %= rv[3]
-                    kw["rowvec"] = torch.cat([rowvec[i0:], rowvec[:i0]], 0).contiguous() if i0 else rowvec
-            self.out(hh, out=out[m0:m1], **kw)
-        return out
+        h = ops.igemm(x, self.w1, self.b1, act=L.ACT_GEGLU_PAIR)
+        return self.out(h, **epilogue)
 
 
 def _sigmoid(v):

@@ -531,66 +531,3 @@ def test_igemm_repeat_launches_bit_identical(ops, N, kinds):
     if "r2" in kinds:
         ref = ref + 0.5 * kw["r2"].float()
     _close(outs[0], ref, tol=4e-3, what="conv + epilogue vs torch fp32")
-
-
-# ---------------------------------------------------------------------------------------------------------
-# blocks.GegluFF: row-chunked feed-forward == the one-pass form, bit for bit (same kernels on the same tiles)
-# ---------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rvkind", ["none", "clip", "frame_periodic"])
-@pytest.mark.parametrize("chunk_rows", [2304, 4608, 5400])
-def test_geglu_ff_row_chunks_bit_identical(ops, rvkind, chunk_rows, monkeypatch):
-    """M = 2 clips x 5 frames x 1152 rows.  chunk_rows 2304: 5 equal passes; 4608: 2 passes + a remainder of 2304 that stays a
-    pass of its own (>= 1/4 chunk); 5400: rounded down to whole units (5376 for the 256-row unit: the remainder of 768 rows
-    joins the last pass).  Row vectors: one row per clip (time-embedding pattern; chunks must start on clip boundaries, so
-    this M runs in one pass) and a frame-periodic table (frame-position embedding: chunks start on frame boundaries and read
-    a rotated table)."""
-    from mofa_video_amd import blocks
-    C, HW, T, B = 320, 1152, 5, 2
-    M, hid = B * T * HW, 4 * C
-    g = torch.Generator().manual_seed(11)
-    sd = {"net.0.proj.weight": torch.randn(2 * hid, C, generator=g) * C ** -0.5, "net.0.proj.bias": torch.randn(2 * hid, generator=g) * 0.1,
-          "net.2.weight": torch.randn(C, hid, generator=g) * hid ** -0.5, "net.2.bias": torch.randn(C, generator=g) * 0.1}
-    ff = blocks.GegluFF(blocks.Sub({k: v.half() for k, v in sd.items()}, "", DEV))
-    x, r1 = _h(M, C, seed=12).to(DEV), _h(M, C, seed=13).to(DEV)
-    kw = dict(r1=r1, s1=1.0)
-    if rvkind == "clip":
-        kw.update(rowvec=torch.randn(B, C, generator=g).to(DEV), rv=(T * HW, 1, 1, blocks.BIG))
-    elif rvkind == "frame_periodic":
-        kw.update(rowvec=torch.randn(T, C, generator=g).to(DEV), rv=(HW, 1, 1, T))
-    # split-K off and the bench's tiles forced for the comparison: whether a launch's last partial round is cut along K depends
-    # on its tile count, and the 4-wave tile the cost model picks for few rows adds the bias after the K sum where the 8-wave
-    # tiles start from it -- either changes the order of an fp32 sum.  With the same kernels the chunking must not change a bit
-    # (on the bench, 65 536-row chunks of 460 800 rows, the choices coincide by themselves)
-    from mofa_video_amd import lib as L
-    launches = []
-    real = ops.igemm
-
-    def counted(xx, *a, **k):
-        launches.append(xx.shape[0])
-        tile = L.TILE_256X256 if k.get("act") == L.ACT_GEGLU_PAIR else L.TILE_256X320
-        return real(xx, *a, **{**k, "split_k": False, "tile": tile})
-    monkeypatch.setattr(ops, "igemm", counted)
-    monkeypatch.setattr(blocks.GegluFF, "CHUNK_ABOVE_BYTES", 1 << 62)
-    ref = ff(x, **kw).clone()
-    assert launches == [M, M]
-    del launches[:]
-    monkeypatch.setattr(blocks.GegluFF, "CHUNK_ABOVE_BYTES", 0)
-    monkeypatch.setattr(blocks.GegluFF, "CHUNK_BYTES", chunk_rows * hid * 2)
-    out = ff(x, **kw)
-    assert sum(launches[0::2]) == M and launches[0::2] == launches[1::2], launches      # every row once, in both GEMMs
-    assert len(launches) >= 4 or rvkind == "clip", launches                              # really chunked
-    if len(launches) > 2:
-        assert min(launches) >= max(launches) // 5, launches                             # no short remainder pass
-    assert torch.equal(out, ref), f"{rvkind} / {chunk_rows}: chunked feed-forward differs from the one-pass form"
-    # and against fp32 torch (the GEGLU kernel with the bias as accumulator start + net.2)
-    w1, b1, w2, b2 = (sd[k].half().float() for k in ("net.0.proj.weight", "net.0.proj.bias", "net.2.weight", "net.2.bias"))
-    b1, b2 = sd["net.0.proj.bias"].half().float(), sd["net.2.bias"].half().float()
-    rows = slice(0, 4096)
-    p = x[rows].float().cpu() @ w1.t() + b1
-    hmid = (p[:, :hid] * F.gelu(p[:, hid:])).half().float()
-    refs = hmid @ w2.t() + b2 + r1[rows].float().cpu()
-    if rvkind == "clip":
-        refs = refs + kw["rowvec"][0].cpu()
-    elif rvkind == "frame_periodic":
-        refs = refs + kw["rowvec"].cpu()[(torch.arange(4096) // HW) % T]
-    _close(out[rows], refs, tol=4e-3, what="chunked GEGLU feed-forward")
