@@ -14,7 +14,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .blocks import BIG, Conv3x3, Ctx, DownBlock, Linear, MidBlock, Sub, TembBatch, TimeEmbedding
+from .blocks import BIG, Conv3x3, Ctx, DownBlock, Linear, MidBlock, Sub, TembBatch, TimeEmbedding, drive
 from .unet import DEFAULT_CONFIG, _Config
 
 
@@ -179,6 +179,10 @@ class FlowControlNet:
         """warped: the list from ``prepare_condition`` (or an ``AdapterCondition`` carrying .warped and, for the
         landmark adapter, .ldmk = {h*w: landmark embedding tokens}).
         -> (12 residual token tensors, mid residual), already multiplied by conditioning_scale."""
+        return drive(self.forward_layers(x, c, H, W, warped, conditioning_scale))
+
+    def forward_layers(self, x, c, H, W, warped, conditioning_scale=1.0):
+        """``forward_tokens`` as a layer generator (blocks.run_lockstep)"""
         B = c.B
         cs = float(conditioning_scale)
         ldmk = getattr(warped, "ldmk", None)
@@ -193,7 +197,7 @@ class FlowControlNet:
         zi += 1                                                              # later in-place adds are safe
         count, length = 1, len(warped)
         for blk in self.down_blocks:
-            sample, H, W, res = blk(sample, c, H, W)
+            sample, H, W, res = yield from blk.layers(sample, c, H, W)
             for (r, _, _) in res:
                 outs.append(self.controlnet_down_blocks[zi](r, s_acc=cs))
                 zi += 1
@@ -201,8 +205,9 @@ class FlowControlNet:
             if ldmk is not None and sample.shape[1] == c0:                   # ldmk_ctrlnet.py:501-504 (== 320)
                 self._add_warped(sample, ldmk[H * W], B)
             count += 1
+            yield
         self._add_warped(sample, warped[-1], B)                              # :354
-        sample = self.mid_block(sample, c, H, W)
+        sample = yield from self.mid_block.layers(sample, c, H, W)
         mid = self.controlnet_mid_block(sample, s_acc=cs)
         return outs, mid
 

@@ -133,6 +133,31 @@ class GegluFF:
         return self.out(h, **epilogue)
 
 
+def drive(gen):
+    """run a layer generator to its end and return its value"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
+def run_lockstep(gens, enter):
+    """Advance several layer generators in turn, one layer each (``enter[i]()`` = the context -- HIP stream, communicator lane --
+    network i is enqueued in), until all are exhausted; returns their values.  ONE host thread issues everything, so the order
+    of the networks' launches and collectives is the program order: the same on every rank by construction."""
+    vals, live = [None] * len(gens), list(range(len(gens)))
+    while live:
+        for i in list(live):
+            with enter[i]():
+                try:
+                    next(gens[i])
+                except StopIteration as stop:
+                    vals[i] = stop.value
+                    live.remove(i)
+    return vals
+
+
 def _sigmoid(v):
     return 1.0 / (1.0 + math.exp(-float(v)))
 
@@ -244,9 +269,8 @@ def _sharded_norm_convt3(norm, conv, x, c, HW, r1=None, **epi):
     nparts = ops.gn_nparts(HW, Cc)
     buf, own = par.part_buffer(nparts, x.device)
     ops.gn_partial_into(x, own, T, HW)
-    with par.turn("norm+conv(3,1,1)"):
-        halo = par.halo_begin(x, HW)
-        par.gather_partials(buf, nparts)
+    halo = par.halo_begin(x, HW)
+    par.gather_partials(buf, nparts)
     cnt = float(par.T_full) * HW * (Cc // 32)
     ext = torch.empty(((T + 2) * HW, Cc), dtype=x.dtype, device=x.device)
     ops.gn_apply_gathered(x, buf, cnt, norm.g, norm.b, norm.eps, ext[HW:(T + 1) * HW], T, HW, silu=True)
@@ -377,8 +401,7 @@ class TransformerSpatioTemporal:
                 # never read by the attention kernel.
                 hid, own = par.kv_buffer(HW, Cc, f.device)
                 fn = self.tnorm1(f, out=own)
-                with par.turn("token gather"):
-                    work = par.kv_gather_begin(hid, HW)
+                work = par.kv_gather_begin(hid, HW)
                 q = self.tattn1.q(fn)
                 work.wait()
                 kv = ops.igemm(hid, self.tattn1.wqkv[Cc:])
@@ -388,8 +411,7 @@ class TransformerSpatioTemporal:
                 fn = self.tnorm1(f)
                 kv, own = par.kv_buffer(HW, 2 * Cc, fn.device)
                 self.tattn1.kv_into(fn, own)
-                with par.turn("K|V gather"):
-                    work = par.kv_gather_begin(kv, HW)
+                work = par.kv_gather_begin(kv, HW)
                 q = self.tattn1.q(fn)
                 work.wait()
                 a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.kv_slots, HW, self.heads,
@@ -401,8 +423,7 @@ class TransformerSpatioTemporal:
                 kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
                 ops.copy2d(k, kv[:, :Cc])
                 ops.copy2d(v, kv[:, Cc:])
-                with par.turn("K|V gather (compacting)"):
-                    kv = par.gather_frames(kv, HW)
+                kv = par.gather_frames(kv, HW)
                 a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.T_full, HW, self.heads,
                                       head_dim=self.tattn1.head_dim, Tq=T)
         # temporal cross-attention row vector.  diffusers 0.24.0 quirk: token row (b, s) of the GLOBAL batch takes the
@@ -430,18 +451,24 @@ class DownBlock:
         self.attns = [TransformerSpatioTemporal(s.sub(f"attentions.{i}"), heads) for i in range(num_layers)] if cross else None
         self.down = Conv3x3(s.sub("downsamplers.0.conv"), stride=2) if downsample else None
 
-    def __call__(self, x, c, H, W):
+    def layers(self, x, c, H, W):
+        """generator: yields after every res (+ transformer) layer -- the points where ``run_lockstep`` switches to the other
+        network of the step; the generator's return value is what ``__call__`` returns"""
         outs = []
         for i, r in enumerate(self.resnets):
             x = r(x, c, H, W)
             if self.attns is not None:
                 x = self.attns[i](x, c, H, W)
             outs.append((x, H, W))
+            yield
         if self.down is not None:
             x = self.down(x, H, W)
             H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
             outs.append((x, H, W))
         return x, H, W, outs
+
+    def __call__(self, x, c, H, W):
+        return drive(self.layers(x, c, H, W))
 
 
 class MidBlock:
@@ -450,8 +477,15 @@ class MidBlock:
         self.attn = TransformerSpatioTemporal(s.sub("attentions.0"), heads)
         self.res1 = SpatioTemporalResBlock(s.sub("resnets.1"), 1e-5)
 
+    def layers(self, x, c, H, W):
+        x = self.res0(x, c, H, W)
+        yield
+        x = self.attn(x, c, H, W)
+        yield
+        return self.res1(x, c, H, W)
+
     def __call__(self, x, c, H, W):
-        return self.res1(self.attn(self.res0(x, c, H, W), c, H, W), c, H, W)
+        return drive(self.layers(x, c, H, W))
 
 
 class UpBlock:

@@ -231,61 +231,10 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         // scores are rescaled by the same factor and the tile's probabilities recomputed) -- the quotient O / l does not
         // depend on the reference, fp16 keeps its relative precision at any magnitude, l and O are fp32.  So the common tile
         // needs no row maximum at all: one compare of the row sum it computes anyway (this kernel is VALU-issue bound).
+        // (r04: the row sums taken from the matrix core instead -- ones[32x16] . P^T, four extra MFMAs per query block and tile,
+        // 132 v_add_f32 fewer -- measured SLOWER, 946 against 972 TF/s on the L0 shape: the sums gate the reference check, so
+        // the PV MFMAs wait for the extra MFMAs' results; profiles/r04_attn_rowsum_mfma_ab.log)
         f16x8 pf[QB][2][2];
-#ifdef MOFA_ATT_SUM_MFMA
-        // The row sums of the probabilities come from the MATRIX core, not from 64 v_add_f32 per query block and tile (this
-        // kernel is bound by VALU issue; the MFMA pipe idles half of the time): ones[32 x 16] . P^T[16 keys x 32 queries], four
-        // k-blocks of the tile accumulated, leaves sum_keys p(key, query l31) in EVERY register of the lane -- both key halves
-        // included (the k index spans both lane halves), so the cross-half exchange goes as well.  The sums are those of the
-        // fp16-rounded probabilities, i.e. exactly the weights O is accumulated with.
-        const f16x8 ones8 = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
-        auto tile_sum = [&](int b) __attribute__((always_inline)) -> float {
-            f32x16 ls;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ls[r] = 0.f;
-#pragma unroll
-            for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) ls = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, pf[b][ts][u], ls, 0, 0, 0);
-            return ls[0];
-        };
-#pragma unroll
-        for (int b = 0; b < QB; ++b) {
-#pragma unroll
-            for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pf[b][ts][r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(s[b][ts][r]);   // raw v_exp_f32
-            float ptot = tile_sum(b);                                       // (inf / NaN when a probability left the fp16 range)
-            const bool move = !(ptot < ATT_DEFER_SUM) || t == 0;           // (NaN-safe; tile 0: m_run = 0 is no reference yet)
-            if (__any(move)) {
-                asm volatile("; reference moves" ::: "memory");
-                float mx = s[b][0][0];
-#pragma unroll
-                for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[b][ts][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float delta = move ? mx : 0.f;
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                m_run[b] += delta;
-                if constexpr (NEGM) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) negm[b][r] = -m_run[b];
-                }
-                l_run[b] *= alpha;
-#pragma unroll
-                for (int db = 0; db < DB; ++db)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[b][db][r] *= alpha;
-#pragma unroll
-                for (int ts = 0; ts < 2; ++ts)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) pf[b][ts][r >> 3][r & 7] = (f16)__builtin_amdgcn_exp2f(s[b][ts][r] - delta);
-                ptot = tile_sum(b);
-            }
-            l_run[b] += ptot;
-        }
-#else
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
             float psum = 0.f;
@@ -332,8 +281,6 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             l_run[b] += psum;
         }
 
-#endif
-
         // ---- O^T[d][q] += V^T[d][key] * P^T[key][q]; k-slot (8*lh + jj) of MFMA (ts,u) = key
         //      32*ts + 16*u + 4*lh + (jj&3) + 8*(jj>>2), identical for both operands ---------------
 #pragma unroll
@@ -359,11 +306,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-#ifdef MOFA_ATT_SUM_MFMA
-        const float l_tot = l_run[b];                         // (already the sum over both key halves)
-#else
         const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32, 64);
-#endif
         const float inv = 1.0f / l_tot;
         const int qi = q0 + b * 32 + l31;
         if (qi < S) {

@@ -701,15 +701,11 @@ int igemm320_split(long long T, int nk, int n_cu, long long ws_bytes) {
     const long long R = T % n_cu;
     if (ws_bytes <= 0 || R == 0) return 1;
     if (T > n_cu && R * 10 > (long long)n_cu * 6) return 1;   // a last round that is more than 60 % full stays whole
-#ifndef MOFA_SPLIT_MAXS
-#define MOFA_SPLIT_MAXS 8
-#endif
-#ifndef MOFA_SPLIT_MINK
-#define MOFA_SPLIT_MINK 8
-#endif
     long long s = n_cu / R;
-    if (s > MOFA_SPLIT_MAXS) s = MOFA_SPLIT_MAXS;
-    if (s > nk / MOFA_SPLIT_MINK) s = nk / MOFA_SPLIT_MINK;    // at least eight K tiles per slice, and ...
+    if (s > 8) s = 8;
+    if (s > nk / 8) s = nk / 8;                                // at least eight K tiles per slice, and ... (r04: up to 16 slices
+                                                               // of >= 4 K tiles changes nothing on the per-rank shapes of an
+                                                               // 8-GPU run: mix 691 against 693 TF/s, profiles/r04_shard_shapes_tiles.log)
     // ... only where it pays: a slice saves (1 - 1 / S) of a tile's K loop (about 2 us per K tile) but costs the partial-tile
     // dump and the fix-up launch (about 25 us; profiles/r03b_kernel_stats_bench.md: splitting the shallow-K launches of the
     // clip -- 5 100 of 12 012 -- made it 4 % SLOWER)

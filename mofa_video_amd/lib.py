@@ -43,7 +43,7 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 # name -> argtypes (every symbol include/mofa_hip.h declares; tests check they all resolve)
 PROTOTYPES = {
     "mofa_version": [],
-    "mofa_igemm_f16": [C.POINTER(IgemmArgs), _P],
+    "mofa_igemm_f16": [_P, _P],                     # (const mofa_igemm_args*: a byref(IgemmArgs) or the packed 184 bytes)
     "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_attn_spatial_qb_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
@@ -121,13 +121,13 @@ def load():
 
 
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """the caller's current torch stream as a plain integer (ctypes converts it for a void* parameter; building c_void_p
+    objects per argument was a measurable part of the host time per launch)"""
+    return torch.cuda.current_stream().cuda_stream
 
 
 def ptr(t):
-    if t is None:
-        return None
-    return C.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()
 
 
 def check(rc, what):

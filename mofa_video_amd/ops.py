@@ -6,6 +6,7 @@ fine).  PyTorch only provides device memory and the stream here; all arithmetic 
 libmofa_hip.so.
 """
 import ctypes as C
+import struct
 import threading
 
 import torch
@@ -129,20 +130,27 @@ def igemm_workspace(device):
     return ws
 
 
+# mofa_igemm_args (include/mofa_hip.h, 184 bytes) packed in one call: the ~40 ctypes field stores of a Structure cost more
+# host time than everything else in this wrapper, and the host's time per launch is what bounds a frame-sharded rank
+_IGEMM_ARGS = struct.Struct("@7P22i3f3iPq")
+assert _IGEMM_ARGS.size == C.sizeof(L.IgemmArgs)
+_TAPS_FIXED = {L.MODE_PLAIN: 1, L.MODE_CONVT3: 3}
+
+
 def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, r2=None, s2=1.0,
           act=L.ACT_NONE, s_acc=1.0, out=None, tile=None, split_k=True):
     """out[m,n] = act(s_acc*(conv/gemm + bias + rowvec[idx(m)]) + s1*r1 + s2*r2).  See include/mofa_hip.h.
     tile: one of lib.TILE_* to force the output tile (parity tests); default = ops.FORCE_TILE = the launcher's model.
     split_k: hand the launcher this stream's scratch buffer so that it may split a partial last round of tiles along K."""
     lib = L.load()
-    _chk(x, F16); _chk(w, F16)
+    assert x.is_cuda and x.dtype is F16 and w.dtype is F16 and w.is_contiguous() and x.stride(1) == 1, "fp16 cuda, unit channel stride"
     N, Ktot = w.shape
-    assert w.is_contiguous()
-    taps = {L.MODE_PLAIN: 1, L.MODE_CONV3X3: geom.ksize * geom.ksize, L.MODE_CONVT3: 3}[geom.mode]
+    mode = geom.mode
+    taps = geom.ksize * geom.ksize if mode == L.MODE_CONV3X3 else _TAPS_FIXED[mode]
     Cin = Ktot // taps
     assert Cin * taps == Ktot and x.shape[1] >= Cin, (x.shape, w.shape, taps)
     if M is None:
-        if geom.mode == L.MODE_CONV3X3:
+        if mode == L.MODE_CONV3X3:
             nimg = x.shape[0] // (geom.Hin * geom.Win)
             assert nimg * geom.Hin * geom.Win == x.shape[0]
             M = nimg * geom.Hout * geom.Wout
@@ -151,54 +159,46 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     n_out = N // 2 if act == L.ACT_GEGLU_PAIR else N
     if out is None:
         out = torch.empty((M, n_out), dtype=F16, device=x.device)
-    _chk(out, F16)
-    assert out.shape[0] == M and out.shape[1] >= n_out
-    a = L.IgemmArgs()
-    a.x, a.w, a.out = x.data_ptr(), w.data_ptr(), out.data_ptr()
-    a.bias = bias.data_ptr() if bias is not None else None
-    a.rowvec = rowvec.data_ptr() if rowvec is not None else None
-    a.r1 = r1.data_ptr() if r1 is not None else None
-    a.r2 = r2.data_ptr() if r2 is not None else None
+    else:
+        assert out.dtype is F16 and out.is_cuda and out.shape[0] == M and out.shape[1] >= n_out and out.stride(1) == 1
+    pb = pv = p1 = p2 = 0
+    ld1 = ld2 = 0
     if bias is not None:
-        _chk(bias, F32); assert bias.numel() == N
+        assert bias.dtype is F32 and bias.numel() == N
+        pb = bias.data_ptr()
     if rowvec is not None:
         # rows of a wider fp32 matrix are allowed: the kernel addresses row idx at idx*N, so the caller's rv_mul must
         # carry the row stride (TembBatch: stride = total, rv_mul = total / N)
-        _chk(rowvec, F32); assert rowvec.dim() == 2 and rowvec.shape[1] == N and rowvec.stride(1) == 1
+        assert rowvec.dtype is F32 and rowvec.dim() == 2 and rowvec.shape[1] == N and rowvec.stride(1) == 1
         assert rowvec.is_contiguous() or (rowvec.stride(0) % N == 0 and rv[1] == rowvec.stride(0) // N), (rowvec.stride(), N, rv)
-    a.M, a.N, a.Cin = M, N, Cin
-    a.ldx, a.ldo = _ld(x), _ld(out)
-    a.ldr1 = _ld(r1) if r1 is not None else 0
-    a.ldr2 = _ld(r2) if r2 is not None else 0
+        pv = rowvec.data_ptr()
     if r1 is not None:
-        _chk(r1, F16); assert r1.shape[0] == M
+        assert r1.dtype is F16 and r1.shape[0] == M and r1.stride(1) == 1
+        p1, ld1 = r1.data_ptr(), r1.stride(0)
     if r2 is not None:
-        _chk(r2, F16); assert r2.shape[0] == M
-    a.mode = geom.mode
-    a.Hin, a.Win, a.Hout, a.Wout, a.stride, a.up = geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up
-    a.ksize = geom.ksize
-    a.dil = geom.dil
-    a.pad = geom.pad
-    a.T, a.HW = geom.T, geom.HW
-    a.rv_div, a.rv_mul, a.rv_mod_in, a.rv_mod_out = rv
-    a.act = act
-    a.s_acc, a.s1, a.s2 = s_acc, s1, s2
-    a.tile = FORCE_TILE if tile is None else tile
+        assert r2.dtype is F16 and r2.shape[0] == M and r2.stride(1) == 1
+        p2, ld2 = r2.data_ptr(), r2.stride(0)
     if split_k:
         ws = igemm_workspace(x.device)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+        pw, nw = ws.data_ptr(), ws.numel()
     else:
-        a.workspace, a.workspace_bytes = None, 0
+        pw = nw = 0
+    args = _IGEMM_ARGS.pack(x.data_ptr(), w.data_ptr(), pb, pv, p1, p2, out.data_ptr(),
+                            M, N, Cin, x.stride(0), out.stride(0), ld1, ld2, mode,
+                            geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up, geom.ksize, geom.T, geom.HW,
+                            rv[0], rv[1], rv[2], rv[3], act, s_acc, s1, s2, geom.dil, geom.pad,
+                            FORCE_TILE if tile is None else tile, pw, nw)
     t0 = TIMER.start() if TIMER is not None else None
     if split_k:
         with _igemm_ws_lock:
-            rc = lib.mofa_igemm_f16(C.byref(a), L.stream_ptr())
+            rc = lib.mofa_igemm_f16(args, L.stream_ptr())
     else:
-        rc = lib.mofa_igemm_f16(C.byref(a), L.stream_ptr())
-    L.check(rc, "mofa_igemm_f16")
+        rc = lib.mofa_igemm_f16(args, L.stream_ptr())
+    if rc != 0:
+        L.check(rc, "mofa_igemm_f16")
     if t0 is not None:
         TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot,
-                   tag=(geom.mode, geom.stride, geom.up, M, N, Ktot, act))
+                   tag=(mode, geom.stride, geom.up, M, N, Ktot, act))
     return out
 
 

@@ -21,10 +21,11 @@ and once per clip: all-gather of the final latents before the VAE decode, whose 
 dealt round-robin to ALL ranks.  Everything per-frame (2-D convs, spatial norms/attention, FFs, the adapter warps,
 zero convs, the Euler step) needs no communication.
 
-With two networks of a step in flight (adapter trunk || UNet encoder, one host thread and HIP stream each) the exchange
-groups are issued in ONE global order on every rank -- trunk's k-th, encoder's k-th, ... -- enforced by ``TurnToken``: a
-collective is only ever issued by the thread that holds the token, so no two ranks can disagree about the order on any
-communicator (the precondition for RCCL not to deadlock) whatever the host timing is.
+With two networks of a step in flight (adapter trunk || UNet encoder on two HIP streams) ONE host thread enqueues both, layer
+by layer in lockstep (blocks.run_lockstep): every rank runs the same program, so every communicator sees the same sequence of
+collectives on every rank -- the precondition for RCCL not to deadlock -- by construction, with no thread, token or timing
+involved; a network's wait for its partials / halo frames / token gather is a STREAM wait that the other network's kernels
+cover, the host never blocks on the transport.
 
 ``Comm`` implementations: ``TorchComm`` (torch.distributed: "nccl" = RCCL on the GPUs, "gloo" in the CPU tests) and
 ``ThreadComm`` (virtual ranks as threads of one process -- lets the whole sharded HIP path be checked against the
@@ -96,15 +97,17 @@ class TorchComm:
             for g in (tuple(lay.frame_group), tuple(lay.pair_group)):
                 if g not in seen:
                     seen.append(g)
-        # per group of ranks three communicators, so that a small latency-bound exchange never queues behind a bulk transfer of
-        # the other network of the step: "" = bulk (token gather, final latents, CFG pair), "ctl" = GroupNorm partials,
-        # "data" = halo frames.  Created by every rank in the same order (a torch.distributed requirement).
-        self._ctl, self._data = {}, {}
+        # per group of ranks four communicators, so that a small latency-bound exchange never queues behind a bulk transfer and
+        # the two networks of a step (lanes 0 / 1) never queue behind each other's token gathers: "" = bulk of lane 0 (token
+        # gather, final latents, CFG pair), "bulk1" = token gather of lane 1, "ctl" = GroupNorm partials, "data" = halo frames.
+        # Created by every rank in the same order (a torch.distributed requirement).
+        self._ctl, self._data, self._bulk1 = {}, {}, {}
         for g in seen:
             many = len(g) > 1
             self._groups[g] = dist.new_group(list(g)) if many else None
             self._ctl[g] = dist.new_group(list(g)) if many else None
             self._data[g] = dist.new_group(list(g)) if many else None
+            self._bulk1[g] = dist.new_group(list(g)) if many else None     # bulk transfers of the step's second network
         self._world_group = None
 
     def _g(self, ranks):
@@ -131,15 +134,15 @@ class TorchComm:
         self.dist.all_gather_into_tensor(flat, t.reshape(-1))
         return list(flat.reshape((n,) + tuple(t.shape)).unbind(0))
 
-    def all_gather_into(self, buf, slot_rows, ranks):
+    def all_gather_into(self, buf, slot_rows, ranks, lane=0):
         """In-place all-gather: ``buf`` [len(ranks) * slot_rows, C] already holds this rank's rows in its own slot; after
         ``wait()`` it holds every rank's.  Asynchronous: RCCL runs the collective on its own stream, kernels launched
         between this call and ``wait()`` overlap it (``wait`` makes the CURRENT stream wait, the host does not block)."""
         if len(ranks) == 1:
             return _Done()
         i = list(ranks).index(self.rank)
-        return self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=self._g(ranks),
-                                                async_op=True)
+        grp = self._bulk1[tuple(ranks)] if lane else self._g(ranks)
+        return self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=grp, async_op=True)
 
     def gather_small_into(self, buf, slot_rows, ranks):
         """the in-place all-gather of ``all_gather_into`` on the "ctl" communicator, complete in stream order when it returns
@@ -244,7 +247,7 @@ class ThreadComm:
     def all_gather_world(self, t):
         return self.all_gather(t, list(range(self.tw.world)))
 
-    def all_gather_into(self, buf, slot_rows, ranks):
+    def all_gather_into(self, buf, slot_rows, ranks, lane=0):
         if len(ranks) == 1:
             return _Done()
         i = list(ranks).index(self.rank)
@@ -269,58 +272,6 @@ class ThreadComm:
 
 
 # ---------------------------------------------------------------------------------------------------------
-class TurnToken:
-    """Issue order of the exchange groups of TWO networks that one rank enqueues from two host threads (adapter trunk = role 0
-    on the second HIP stream, UNet encoder = role 1 on the caller's): a thread issues collectives only while it holds the
-    token, passes it on after every exchange group and gets it back after the other thread's next group -- trunk's k-th, then
-    encoder's k-th, ... -- and a thread that has finished hands it over for good.  The resulting global order depends on the
-    program alone (both threads run the same code on every rank), never on host timing, so all ranks issue the same sequence
-    on every communicator: the condition under which RCCL cannot deadlock.  ``log`` records (role, tag) per group (tests)."""
-
-    def __init__(self, first=0, timeout=180.0, enforce=True):
-        self.cv = threading.Condition()
-        self.holder, self.active, self.timeout, self.enforce = first, [True, True], timeout, enforce
-        self.log = []
-
-    def acquire(self, role):
-        if not self.enforce:                                   # (tests: what the log looks like WITHOUT the token)
-            return
-        with self.cv:
-            while self.holder != role and self.active[1 - role]:
-                if not self.cv.wait(self.timeout):
-                    raise RuntimeError(f"turn token: role {role} waited {self.timeout} s for its turn (the other network's "
-                                       "thread died or issued fewer exchange groups than this rank's peers expect)")
-            self.holder = role
-
-    def release(self, role, tag=None):
-        with self.cv:
-            self.log.append((role, tag))
-            if self.enforce and self.active[1 - role]:
-                self.holder = 1 - role
-            self.cv.notify_all()
-
-    def finish(self, role):
-        with self.cv:
-            self.active[role] = False
-            if self.holder == role:
-                self.holder = 1 - role
-            self.cv.notify_all()
-
-
-class _Turn:
-    def __init__(self, tok, role, tag):
-        self.tok, self.role, self.tag = tok, role, tag
-
-    def __enter__(self):
-        if self.tok is not None:
-            self.tok.acquire(self.role)
-
-    def __exit__(self, *exc):
-        if self.tok is not None:
-            self.tok.release(self.role, self.tag)
-        return False
-
-
 class FrameParallel:
     """The per-rank object blocks consult (``Ctx.par``) when a clip's frames are sharded."""
 
@@ -330,25 +281,15 @@ class FrameParallel:
         self.p2p = p2p
         self.kv_inplace = True      # temporal attention K|V: in-place asynchronous all_gather_into_tensor (else: compacting gather)
         self.gather_hidden = True   # ... of the normed hidden tokens (C columns; K|V projected after the gather) instead of K|V (2C)
-        self.two_streams = True     # adapter trunk || UNet encoder on two host threads / HIP streams under a TurnToken
-        self.split_convs = True     # (3,1,1) convolutions as interior + boundary launches (the halo frames travel meanwhile)
-        self._tls = threading.local()
+        self.two_streams = True     # adapter trunk || UNet encoder on two HIP streams, enqueued layer by layer in lockstep
+        self.split_convs = False    # (3,1,1) convolutions as interior + boundary launches while the halo frames travel: OFF --
+                                    # on the 1-GPU proxy of a rank of 8 the extra launches cost 3.1 ms of a 49 ms step while
+                                    # all halo frames of a step are <= 2.5 ms of wire time that the second network already
+                                    # covers (profiles/r04_shard_proxy.log); kept for links slower than xGMI
+        self.lane = 0               # which network of the step is being enqueued (0 / 1): selects the bulk communicator and
+                                    # the cached exchange buffers, so the two networks never queue behind each other
         self._part_bufs = {}
-
-    # two networks in flight: issue order of their exchange groups --------------------------------------------
-    def bind(self, token, role):
-        """this host thread enqueues network ``role`` (0 = adapter trunk, 1 = UNet encoder) under ``token``"""
-        self._tls.token, self._tls.role = token, role
-
-    def unbind(self):
-        tok, role = getattr(self._tls, "token", None), getattr(self._tls, "role", 0)
-        self._tls.token = None
-        if tok is not None:
-            tok.finish(role)
-
-    def turn(self, tag=None):
-        """context of ONE exchange group: entered when it is this thread's turn, passes the token on when left"""
-        return _Turn(getattr(self._tls, "token", None), getattr(self._tls, "role", 0), tag)
+        self.log = None             # tests: list that receives (lane, kind) of every exchange issued
 
     def self_check(self, device):
         """Runs the two transport-specific fast paths once on small known data -- the in-place asynchronous
@@ -417,11 +358,10 @@ class FrameParallel:
     def part_buffer(self, nparts, device):
         """-> (buf fp32 [frame_ranks * T_max * nparts, 64], own = this shard's [T_loc * nparts, 64] rows of it): the gather
         buffer of the GroupNorm partials of one clip (one entry of 32 x {sum, sum of squares} per frame and row chunk).
-        Cached per (network role, stream, nparts) and zero-filled once: ``mofa_gn_partial_f16`` rewrites the own rows every
+        Cached per (network lane, stream, nparts) and zero-filled once: ``mofa_gn_partial_f16`` rewrites the own rows every
         time, the padding rows of a shorter shard stay zero (they are gathered and summed like any entry)."""
         lay = self.lay
-        key = (getattr(self._tls, "role", 0), torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0, nparts,
-               str(device))
+        key = (self.lane, torch.cuda.current_stream().cuda_stream if device.type == "cuda" else 0, nparts, str(device))
         buf = self._part_bufs.get(key)
         if buf is None:
             buf = torch.zeros((lay.frame_ranks * lay.T_max * nparts, 64), dtype=torch.float32, device=device)
@@ -431,6 +371,8 @@ class FrameParallel:
 
     def gather_partials(self, buf, nparts):
         """all ranks' partials into ``buf`` (in place; complete in stream order on return)"""
+        if self.log is not None:
+            self.log.append((self.lane, "partials"))
         return self.comm.gather_small_into(buf, self.lay.T_max * nparts, self.lay.frame_group)
 
     # temporal conv halo -----------------------------------------------------------------------------------
@@ -439,6 +381,8 @@ class FrameParallel:
         (frame before this shard, frame after it), None at the clip ends (= the convolution's zero padding)."""
         lay = self.lay
         first, last = x[:HW], x[(self.T_loc - 1) * HW:]
+        if self.log is not None:
+            self.log.append((self.lane, "halo"))
         if self.p2p:
             return self.comm.halo_begin(first, last, lay.prev_rank, lay.next_rank, lay.frame_group)
         got = self.comm.all_gather(torch.cat([first, last], 0), lay.frame_group)      # conservative path (self_check)
@@ -469,7 +413,9 @@ class FrameParallel:
         return buf, buf[lay.shard * slot:lay.shard * slot + self.T_loc * rows_per_frame]
 
     def kv_gather_begin(self, buf, rows_per_frame):
-        return self.comm.all_gather_into(buf, self.lay.T_max * rows_per_frame, self.lay.frame_group)
+        if self.log is not None:
+            self.log.append((self.lane, "tokens"))
+        return self.comm.all_gather_into(buf, self.lay.T_max * rows_per_frame, self.lay.frame_group, lane=self.lane)
 
     def gather_frames(self, t, rows_per_frame):
         """t [T_loc*rows, C] (this shard's frames) -> [T_full*rows, C] in frame order (uneven shards are padded to

@@ -129,8 +129,8 @@ class FlowControlNetPipeline:
         """``adapters``: [(controlnet, its Ctx, its per-clip condition, conditioning scale)], one entry, or two (face, drag)
         whose residuals are blended by ``masks`` (Hybrid/pipeline/pipeline.py:479-489) -> the UNet's noise prediction (tokens).
         Without frame sharding the trunks run on ``self._adapter_stream`` while the UNet's encoder half runs on the caller's
-        stream; the streams join before the residuals are added (unet.decode_tokens).  Frame-sharded ranks do the same with a
-        second host thread and a turn token that fixes the issue order of their exchanges (_denoise_forward_sharded)."""
+        stream; the streams join before the residuals are added (unet.decode_tokens).  Frame-sharded ranks enqueue the two
+        networks layer by layer in lockstep so that their exchanges are issued in program order (_denoise_forward_sharded)."""
         unet = self.unet
 
         def trunks():
@@ -148,7 +148,7 @@ class FlowControlNetPipeline:
             unet.make_ctx(t, emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
             return unet.forward_tokens(x_loc, c_un, h, w, down, mid)
         if fpar is not None:
-            return self._denoise_forward_sharded(trunks, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, c_un)
+            return self._denoise_forward_sharded(adapters, masks, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, c_un)
         cur = torch.cuda.current_stream(self.device)
         if self._adapter_stream is None:
             self._adapter_stream = torch.cuda.Stream(device=self.device)
@@ -186,48 +186,51 @@ class FlowControlNetPipeline:
         outs[1].record_stream(cur)
         return torch.cat(outs, 0)
 
-    def _denoise_forward_sharded(self, trunks, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, c_un):
+    def _denoise_forward_sharded(self, adapters, masks, x_loc, t, emb, added_time_ids, Bl, Tl, half, fpar, h, w, c_un):
         """Frame-sharded ranks: trunk(s) and UNet encoder still overlap on two HIP streams, but both issue collectives, and all
-        ranks must issue them in one order.  The trunk is therefore enqueued by a second HOST THREAD on the second stream and
-        the two threads take turns at every exchange group under a ``parallel.TurnToken`` (trunk's k-th, encoder's k-th, ...):
-        each network's wait for its GroupNorm partials / halo frames / token gather is covered by the other network's kernels.
-        The decoder half runs on the caller's stream alone, as on a single GPU."""
-        import threading
-        from .parallel import TurnToken
+        ranks must issue them in one order.  ONE host thread therefore enqueues both networks layer by layer in lockstep
+        (blocks.run_lockstep: a trunk layer on the second stream, the matching encoder layer on the caller's, ...): the order
+        is the program order on every rank, each network's wait for its GroupNorm partials / halo frames / token gather is a
+        stream wait covered by the other network's kernels, and the host never blocks (a second host thread under a turn
+        token gave the same order at 2.3 x the host time per step, profiles/r04_shard_proxy.log).  The decoder half runs on the
+        caller's stream alone."""
+        import contextlib
+        from .blocks import run_lockstep
         unet, dev = self.unet, self.device
         cur = torch.cuda.current_stream(dev)
         if self._adapter_stream is None:
             self._adapter_stream = torch.cuda.Stream(device=dev)
         side = self._adapter_stream
         side.wait_stream(cur)
-        tok = TurnToken(first=0)
-        box = {}
-        dev_index = torch.cuda.current_device()                 # (self.device may carry no index; the new thread needs one)
 
-        def trunk_thread():
-            try:
-                torch.cuda.set_device(dev_index)
-                fpar.bind(tok, 0)
-                with torch.no_grad(), torch.cuda.stream(side):
-                    box["res"] = trunks()
-            except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
-                box["err"] = e
-            finally:
-                fpar.unbind()
-                tok.finish(0)                                   # whatever happened: the encoder must never wait for a dead trunk
-        th = threading.Thread(target=trunk_thread, name="mofa-adapter-trunk")
-        th.start()
-        try:
-            fpar.bind(tok, 1)
+        def trunk_layers():
+            res = []
+            for net, ctx, cond, scale in adapters:
+                net.make_ctx(t, emb, added_time_ids, Bl, Tl, base=ctx, half=half, par=fpar)
+                res.append((yield from net.forward_layers(x_loc, ctx, h, w, cond, scale)))
+            down, mid = res[0]
+            if len(res) == 2:
+                down, mid = _blend_residuals(down, mid, res[1][0], res[1][1], masks, Bl * Tl)
+            return down, mid
+
+        def encoder_layers():
             unet.make_ctx(t, emb, added_time_ids, Bl, Tl, base=c_un, half=half, par=fpar)
-            enc = unet.encode_tokens(x_loc, c_un, h, w)
+            return (yield from unet.encode_layers(x_loc, c_un, h, w))
+
+        @contextlib.contextmanager
+        def on_side():
+            fpar.lane = 0
+            with torch.cuda.stream(side):
+                yield
+
+        @contextlib.contextmanager
+        def on_cur():
+            fpar.lane = 1
+            yield
+        try:
+            (down, mid), enc = run_lockstep([trunk_layers(), encoder_layers()], [on_side, on_cur])
         finally:
-            fpar.unbind()
-            tok.finish(1)
-            th.join()
-        if "err" in box:
-            raise box["err"]
-        down, mid = box["res"]
+            fpar.lane = 0
         cur.wait_stream(side)
         for r in list(down) + [mid]:
             r.record_stream(cur)

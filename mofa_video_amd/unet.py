@@ -8,7 +8,7 @@ entry the pipeline uses (token-major fp16 in/out).
 import torch
 
 from . import ops
-from .blocks import BIG, Conv3x3, Ctx, DownBlock, GroupNorm, MidBlock, Sub, TembBatch, TimeEmbedding, UpBlock
+from .blocks import BIG, Conv3x3, Ctx, DownBlock, GroupNorm, MidBlock, Sub, TembBatch, TimeEmbedding, UpBlock, drive
 
 SVD_XT_HEADS = (5, 10, 20, 20)
 DEFAULT_CONFIG = dict(in_channels=8, out_channels=4, block_out_channels=(320, 640, 1280, 1280),
@@ -105,18 +105,23 @@ class UNetSpatioTemporalConditionControlNetModel:
         tensor.  Returns fp16 [B*T*H*W, 4] noise prediction (token-major)."""
         return self.decode_tokens(self.encode_tokens(x, c, H, W), c, down_res, mid_res)
 
-    def encode_tokens(self, x, c, H, W):
-        """conv_in + down blocks + mid block: the part of the forward that does not depend on the adapter's residuals (the
-        ControlNet trunk of the same step is independent of it)"""
+    def encode_layers(self, x, c, H, W):
+        """conv_in + down blocks + mid block as a layer generator (blocks.run_lockstep); returns what ``encode_tokens`` returns"""
         sample = self.conv_in(x, H, W)
         skips = [sample]
         counts = []
         for blk in self.down_blocks:
-            sample, H, W, outs = blk(sample, c, H, W)
+            sample, H, W, outs = yield from blk.layers(sample, c, H, W)
             skips += [o[0] for o in outs]
             counts.append(len(skips))
-        sample = self.mid_block(sample, c, H, W)
+            yield
+        sample = yield from self.mid_block.layers(sample, c, H, W)
         return sample, skips, counts, H, W
+
+    def encode_tokens(self, x, c, H, W):
+        """conv_in + down blocks + mid block: the part of the forward that does not depend on the adapter's residuals (the
+        ControlNet trunk of the same step is independent of it)"""
+        return drive(self.encode_layers(x, c, H, W))
 
     def decode_tokens(self, enc, c, down_res, mid_res):
         sample, skips, counts, H, W = enc

@@ -200,59 +200,58 @@ def _reference_block(full, norm, conv, T, HW, C, res=None, s_acc=1.0):
     return o + res.float() if res is not None else o
 
 
-def _block_worker(rank, world, port, T, HW, C, two_threads):
+def _block_worker(rank, world, port, T, HW, C, two_networks):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import threading
+        import contextlib
         import time
         import emu_ops
         from mofa_video_amd import blocks
-        from mofa_video_amd.parallel import TurnToken
         emu_ops.install()
         lay = Layout(world, rank, T, cfg_ranks=1)
         par = FrameParallel(lay, TorchComm(lambda r: Layout(world, r, T, cfg_ranks=1)))
         c = blocks.Ctx(1, lay.T_loc)
         c.par = par
 
-        def network(seed, nblocks, role=None, tok=None, out=None, delay=0.0):
+        def network(seed, nblocks, errs, delay=0.0):
+            """layer generator: ``nblocks`` sharded norm + conv(3,1,1) blocks on seeded data, checked against the whole clip"""
             g = torch.Generator().manual_seed(seed)
-            if tok is not None:
-                par.bind(tok, role)
-            try:
-                errs = []
-                for k in range(nblocks):
-                    full = (torch.randn(T * HW, C, generator=g) * 1.5 + 0.3).half()
-                    res = torch.randn(T * HW, C, generator=g).half()
-                    n1, c1 = _Norm(C, g), _Conv(C, g)
-                    time.sleep(delay * ((k + rank) % 3))                                       # perturb the host timing per rank
-                    mine, rmine = full[lay.f0 * HW:lay.f1 * HW].contiguous(), res[lay.f0 * HW:lay.f1 * HW].contiguous()
-                    got = blocks._sharded_norm_convt3(n1, c1, mine, c, HW, r1=rmine, s1=1.0, s_acc=0.7)
-                    ref = _reference_block(full, n1, c1, T, HW, C, res, 0.7)[lay.f0 * HW:lay.f1 * HW]
-                    errs.append(float((got.float() - ref).abs().max()))
-                if out is not None:
-                    out[role] = errs
-                return errs
-            finally:
-                if tok is not None:
-                    par.unbind()
-        if not two_threads:
+            for k in range(nblocks):
+                full = (torch.randn(T * HW, C, generator=g) * 1.5 + 0.3).half()
+                res = torch.randn(T * HW, C, generator=g).half()
+                n1, c1 = _Norm(C, g), _Conv(C, g)
+                time.sleep(delay * ((k + rank) % 3))                                       # perturb the host timing per rank
+                mine, rmine = full[lay.f0 * HW:lay.f1 * HW].contiguous(), res[lay.f0 * HW:lay.f1 * HW].contiguous()
+                got = blocks._sharded_norm_convt3(n1, c1, mine, c, HW, r1=rmine, s1=1.0, s_acc=0.7)
+                ref = _reference_block(full, n1, c1, T, HW, C, res, 0.7)[lay.f0 * HW:lay.f1 * HW]
+                errs.append(float((got.float() - ref).abs().max()))
+                yield
+            return errs
+        if not two_networks:
             for split in (True, False):
                 par.split_convs = split
-                errs = network(7, 3)
+                errs = blocks.drive(network(7, 3, []))
                 assert max(errs) < 2e-2, (rank, split, errs)
         else:
-            # two networks on two host threads, issue order fixed by the turn token; different block counts and per-rank
-            # delays (rank 0 slows its trunk, rank 1 its encoder): without a common order gloo would pair the wrong collectives
-            tok, out = TurnToken(first=0, timeout=120.0), {}
-            th = threading.Thread(target=network, args=(11, 4, 0, tok, out, 0.02 if rank == 0 else 0.0))
-            th.start()
-            network(12, 6, 1, tok, out, 0.02 if rank == 1 else 0.0)
-            th.join()
-            assert max(out[0]) < 2e-2 and max(out[1]) < 2e-2, (rank, out)
-            assert len(out[0]) == 4 and len(out[1]) == 6
-            order = [r for r, _ in tok.log]
-            assert order == [0, 1] * 4 + [1, 1], (rank, order)                                  # trunk k, encoder k, ...; then the rest
+            # two networks of different length enqueued in lockstep by ONE thread, as pipeline._denoise_forward_sharded does:
+            # every rank issues the same sequence of exchanges whatever its host timing is (the ranks are delayed differently)
+            par.log = []
+
+            def lane(i):
+                @contextlib.contextmanager
+                def cm():
+                    par.lane = i
+                    yield
+                return cm
+            e0, e1 = blocks.run_lockstep([network(11, 4, [], 0.02 if rank == 0 else 0.0), network(12, 6, [], 0.02 if rank == 1 else 0.0)],
+                                         [lane(0), lane(1)])
+            assert max(e0) < 2e-2 and max(e1) < 2e-2 and len(e0) == 4 and len(e1) == 6, (rank, e0, e1)
+            want = [(ln, kind) for k in range(4) for ln in (0, 1) for kind in ("halo", "partials")] + [(1, "halo"), (1, "partials")] * 2
+            assert par.log == want, (rank, par.log)
+            logs = [None] * world
+            dist.all_gather_object(logs, par.log)
+            assert all(lg == logs[0] for lg in logs)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -264,44 +263,35 @@ def test_sharded_temporal_block_gloo(world, T):
     mp.spawn(_block_worker, args=(world, _free_port(), T, 6, 32, False), nprocs=world, join=True)
 
 
-def test_two_networks_turn_token_gloo():
+def test_two_networks_in_lockstep_gloo():
     mp.spawn(_block_worker, args=(2, _free_port(), 9, 6, 32, True), nprocs=2, join=True)
 
 
-def test_turn_token_order_is_timing_independent():
-    """the issue order of two threads' exchange groups: with the token it is trunk k, encoder k, ... whatever the host timing;
-    without it (enforce=False, the sabotaged order) two 'ranks' with different delays log DIFFERENT orders -- which on a real
-    transport means mismatched collectives"""
-    import threading
-    import time
-    from mofa_video_amd.parallel import TurnToken
+def test_run_lockstep_order_and_values():
+    """blocks.run_lockstep: one layer of each live generator in turn, each inside its own context; values returned in order"""
+    import contextlib
+    from mofa_video_amd.blocks import drive, run_lockstep
+    trace = []
 
-    def run(enforce, slow_role):
-        tok = TurnToken(first=0, enforce=enforce, timeout=30.0)
+    def gen(name, n):
+        for k in range(n):
+            trace.append((name, k, ctx[0]))
+            yield
+        return name * n
 
-        def net(role, n):
-            for k in range(n):
-                if role == slow_role:
-                    time.sleep(0.01)
-                tok.acquire(role)
-                tok.release(role, k)
-            tok.finish(role)
-        a = threading.Thread(target=net, args=(0, 5))
-        b = threading.Thread(target=net, args=(1, 5))
-        a.start(); b.start(); a.join(); b.join()
-        return [r for r, _ in tok.log]
-    want = [0, 1] * 5
-    assert run(True, 0) == want and run(True, 1) == want and run(True, None) == want
-    assert run(False, 0) != run(False, 1)
+    ctx = [None]
 
-
-def test_turn_token_times_out_instead_of_hanging():
-    from mofa_video_amd.parallel import TurnToken
-    tok = TurnToken(first=0, timeout=0.2)
-    with pytest.raises(RuntimeError, match="turn token"):
-        tok.acquire(1)                       # role 0 holds the token and never issues anything
-    tok.finish(0)
-    tok.acquire(1)                           # ... and a finished partner hands it over for good
+    def enter(tag):
+        @contextlib.contextmanager
+        def cm():
+            ctx[0] = tag
+            yield
+            ctx[0] = None
+        return cm
+    vals = run_lockstep([gen("a", 2), gen("b", 4)], [enter("A"), enter("B")])
+    assert vals == ["aa", "bbbb"]
+    assert trace == [("a", 0, "A"), ("b", 0, "B"), ("a", 1, "A"), ("b", 1, "B"), ("b", 2, "B"), ("b", 3, "B")]
+    assert drive(gen("c", 3)) == "ccc"
 
 
 def test_grouped_layout_and_window_cost_table():

@@ -1,6 +1,5 @@
 """One rank of an N-GPU frame-sharded run, alone on ONE GPU: what a rank of the 2-way CFG x N/2 frame-shard layout computes per
-denoise step (its CFG half, its frames, per-rank kernel shapes, interior / boundary convolution launches, the two-thread turn
-token) with every exchange answered locally by a LOOPBACK transport -- peers' data = copies of this rank's own, zero latency.
+denoise step (its CFG half, its frames, per-rank kernel shapes, the two networks enqueued in lockstep on two streams) with every exchange answered locally by a LOOPBACK transport -- peers' data = copies of this rank's own, zero latency.
 Device time per step of this proxy is a LOWER bound of a real rank's step time (no wire time, no waiting for peers), so
 
     t(1 GPU) / (N * t_proxy)   is an UPPER bound of the strong-scaling efficiency at N GPUs,
@@ -37,7 +36,7 @@ class LoopbackComm:
     def all_gather_world(self, t):
         return [t]
 
-    def all_gather_into(self, buf, slot_rows, ranks):
+    def all_gather_into(self, buf, slot_rows, ranks, lane=0):
         i = list(ranks).index(self.rank)
         for j in range(len(ranks)):
             if j != i:
@@ -58,15 +57,18 @@ def main():
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--single-stream", action="store_true", help="trunk and encoder one after the other (FrameParallel.two_streams = False)")
-    ap.add_argument("--no-split", action="store_true", help="(3,1,1) convolutions as one launch after the halo frames arrived")
+    ap.add_argument("--split-convs", action="store_true", help="(3,1,1) convolutions as interior + boundary launches")
+    ap.add_argument("--geometry", default="", help="HxWxT, e.g. 64x64x8: same launches, negligible device work -> the enqueue time IS the host cost")
     args = ap.parse_args()
+    if args.geometry:
+        bench.H, bench.W, bench.T = (int(v) for v in args.geometry.split("x"))
     dev = torch.device("cuda", 0)
     pipe = bench.build_pipeline(dev)
     inp = bench.synthetic_inputs(dev)
     lay = Layout(args.world, args.rank, bench.T)
     par = FrameParallel(lay, LoopbackComm(args.rank))
     par.two_streams = not args.single_stream
-    par.split_convs = not args.no_split
+    par.split_convs = args.split_convs
     pipe.parallel = par if args.world > 1 else None
 
     def run(n):
@@ -86,7 +88,7 @@ def main():
     enq = (res[1 + args.steps][0] - res[1][0]) / args.steps
     gpu = (res[1 + args.steps][1] - res[1][1]) / args.steps
     print(f"rank {args.rank} of {args.world} (CFG half {lay.half}, frames {lay.f0}..{lay.f1 - 1} of {bench.T}, {bench.H}x{bench.W}; "
-          f"{'two streams + turn token' if par.two_streams else 'one stream'}, convs {'interior + boundary' if par.split_convs else 'whole'}; "
+          f"{'two streams, lockstep' if par.two_streams else 'one stream'}, convs {'interior + boundary' if par.split_convs else 'whole'}; "
           f"loopback transport): per denoise step host enqueue {enq * 1e3:.1f} ms, device {gpu * 1e3:.1f} ms")
 
 
