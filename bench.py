@@ -273,6 +273,61 @@ def _cpu_baseline_worker():
                           tflop_vae=fcv.get_total_flops() / 1e12)))
 
 
+def _cpu_baseline_full_worker():
+    """--cpu-baseline-full: ONE denoise step of the oracle at the FULL configuration (25 f 576x1024, CFG batch 2: adapter +
+    ControlNet trunk + UNet, 218.58 TFLOP by the work model) on the host cores, timed once (SURVEY 8d's own prescription; the
+    default bench uses the bounded 8 f x 256x256 sample instead because this takes minutes).  Prints one JSON line."""
+    from oracle.controlnet import FlowControlNet
+    from oracle.unet import UNetSpatioTemporalConditionControlNetModel
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, int(os.environ.get("MOFA_CPU_BASELINE_THREADS", "64"))))
+    torch.set_num_threads(cores)
+    with torch.device("meta"):
+        u, c = UNetSpatioTemporalConditionControlNetModel(), FlowControlNet()
+    u, c = u.to_empty(device="cpu"), c.to_empty(device="cpu")
+    with torch.no_grad():
+        for m in (u, c):
+            for name, p in m.named_parameters():
+                if p.dim() > 1:
+                    n = p.numel()
+                    p.view(-1).copy_((torch.arange(n, dtype=torch.float32) % 251 - 125.0) * (p[0].numel() ** -0.5 / 125.0))
+                elif name.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, T, 8, H // 8, W // 8, generator=g)
+    emb = torch.randn(2, 1, 1024, generator=g)
+    ids = torch.tensor([[6.0, 128.0, 0.02]] * 2)
+    cond = torch.rand(2, 3, H, W, generator=g)
+    flow = torch.randn(2, T - 1, 2, H, W, generator=g)
+    t0 = time.time()
+    with torch.no_grad():
+        dr, mr, _, _ = c(x, torch.tensor(1.0), emb, ids, controlnet_cond=cond, controlnet_flow=flow, return_dict=False)
+        t1 = time.time()
+        u(x, torch.tensor(1.0), emb, down_block_additional_residuals=dr, mid_block_additional_residual=mr, return_dict=False,
+          added_time_ids=ids)
+    t2 = time.time()
+    print(json.dumps(dict(cores=cores, avail=avail, adapter_s=t1 - t0, unet_s=t2 - t1, step_s=t2 - t0, step_tflop=218.58)))
+
+
+def cpu_baseline_full(timeout=3000):
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import bench; bench._cpu_baseline_full_worker()"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=timeout)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rate = d["step_tflop"] / d["step_s"]
+    return dict(kind="port", cores=d["cores"], unit="denoised frames/sec",
+                value=25.0 / (25 * d["step_s"] + 173.57 / 1.06),
+                sample=(f"oracle (fp32 torch CPU, {d['cores']} threads of {d['avail']}): ONE full-size denoise step, 25 f 576x1024, CFG 2 "
+                        f"(adapter + ControlNet trunk {d['adapter_s']:.0f} s, UNet {d['unet_s']:.0f} s = {d['step_s']:.0f} s for 218.58 TFLOP "
+                        f"= {rate:.3f} TFLOP/s); value = 25 frames / (25 x that step + 173.57 TFLOP of decode at the 1.06 TFLOP/s of "
+                        "the default sample's VAE part)"))
+
+
 def cpu_baseline(timeout=420):
     """The CPU oracle (fp32 PyTorch restatement of the reference pipeline, oracle/) on a BOUNDED sample of the same
     workload, two parts: ONE denoise step (MOFA-Adapter/ControlNet + UNet, CFG batch 2) of the full-size SVD-XT architecture
@@ -307,6 +362,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="no GPU work: time ONE full-size denoise step of the CPU oracle (25 f 576x1024; several minutes) and print "
+                         "the cpu_baseline object it yields (kept under profiles/)")
     ap.add_argument("--no-launch-timer", action="store_true",
                     help="A/B switch: do not bracket the launches with HIP events (the line then carries no live roofline leg); "
                          "measures what the event records cost inside the timed region")
@@ -328,6 +386,9 @@ def main():
     ap.add_argument("--lib", default="", help="A/B switch: load this build of libmofa_hip.so instead of the in-tree one "
                     "(same-box comparison of two kernel builds; the path is echoed in config.library)")
     args = ap.parse_args()
+    if args.cpu_baseline_full:
+        print(json.dumps(cpu_baseline_full()))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -548,7 +548,8 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (kind != 7) {
             // 256x320 (igemm320.hip): 0.58 per area (10 % less LDS-DMA, 7 % fewer fragment reads per flop than 256x256); its
             // epilogues move 25 % more outputs per tile
-            static const double epi320[9] = {3.0, 9.0, 10.0, 11.5, 3.5, 9.4, 10.5, 12.0, 5.0};   // fitted: profiles/r03_igemm_tiles_bench.log;
+            static const double epi320[9] = {3.0, 7.5, 8.5, 9.5, 3.5, 7.9, 9.0, 12.0, 5.0};   // fitted: profiles/r03_igemm_tiles_bench.log; r04: the
+            // residual kinds [1] [2] [3] [5] [6] lowered by 1.5-2 with the fp16-transposed residual epilogue (profiles/r04_res16_tiles_ab.log);
             // [1], [5] lowered from 10.0 / 10.5 in r03c so that the K = N = 320 residual launches leave the 192x128 tile (alone a
             // draw: 352-414 against 372-403 TF/s by box; in the clip - 0.27 %, profiles/r03c_cost_model_and_splitk_ab.log:
             // beside a second stream the 17 % of padded columns of 3 x 128 are no longer free)

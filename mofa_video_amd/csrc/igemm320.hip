@@ -356,6 +356,112 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         }
         wait_lds();
     };
+    // ---- residual(s) without a per-row vector (r04): the light epilogue's fp16 pair transposes -- whole 128-byte lines per store,
+    //      half the LDS traffic of the fp32 32 x 32 transposes of epilogue_rows below -- and the residual(s) added in the ROW
+    //      layout afterwards: a lane holds 8 consecutive columns of one row, i.e. exactly one 16-byte residual load.  The
+    //      accumulator is rounded to fp16 BEFORE the add, which is what the reference's fp16 modules do (the layer's output in
+    //      fp16, then `+`); with one residual and s1 == 1 (every residual add of the networks except the AlphaBlender mixes) the
+    //      add is 4 v_pk_add_f16 per 8 outputs.  A ring of D residual pieces is in flight ahead of the transposes. --------------
+    auto epilogue_res16 = [&](auto wnc, auto unit, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
+        constexpr int J0 = (NJ3 == 5 && decltype(wnc)::v) ? 1 : 0;   // first tile of the first pair
+        constexpr int JS = decltype(wnc)::v ? 0 : 4;                 // NJ = 5: the tile without a partner
+        constexpr bool UNIT = decltype(unit)::v != 0;                // one residual, s1 == 1: packed fp16 adds
+        constexpr int PPI = NJ3 == 5 ? 10 : 8, NP = MI3 * PPI;       // store pieces (16 bytes per lane) per row tile / per tile
+        const int lane_e = lane_now();
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
+        f16* out = (f16*)a.out;
+        const f16* r1 = (const f16*)a.r1;
+        const f16* r2 = (const f16*)a.r2;
+        float s1v = a.s1, s2v = a.s2, saccv = a.s_acc;
+        asm volatile("" : "+v"(s1v), "+v"(s2v), "+v"(saccv));
+        // piece q of row tile i: q < 8 -> pair q / 4, rows 8 (q % 4) + lane / 8, columns 8 (lane % 8) of the pair's 64;
+        //                       q >= 8 -> the single tile, rows 16 (q - 8) + lane / 4, columns 8 (lane % 4) of its 32
+        auto piece_pos = [&](int st, int& mr, int& n) __attribute__((always_inline)) {
+            const int i = st / PPI, q = st % PPI;
+            if (q < 8) {
+                mr = mw + 32 * i + 8 * (q & 3) + (lane >> 3);
+                n = nw + 32 * (J0 + 2 * (q >> 2)) + 8 * (lane & 7);
+            } else {
+                mr = mw + 32 * i + 16 * (q - 8) + (lane >> 2);
+                n = nw + 32 * JS + 8 * (lane & 3);
+            }
+        };
+        constexpr int D = (R1 && R2) ? 2 : 5;
+        f16x8 L1[D], L2[D];
+        auto piece_loads = [&](int st, int slot) __attribute__((always_inline)) {
+            int mr, n;
+            piece_pos(st, mr, n);
+            mr = mr < a.M ? mr : a.M - 1;
+            n = n + 8 <= a.N ? n : 0;
+            if (R1) L1[slot] = *(const f16x8*)(r1 + (size_t)mr * a.ldr1 + n);
+            if (R2) L2[slot] = *(const f16x8*)(r2 + (size_t)mr * a.ldr2 + n);
+        };
+#pragma unroll
+        for (int st = 0; st < D; ++st) piece_loads(st, st);
+        auto finish = [&](int st, f16x8 o) __attribute__((always_inline)) {
+            int mr, n;
+            piece_pos(st, mr, n);
+            if constexpr (UNIT) {
+                o = o + L1[st % D];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = (float)o[e];
+                    if (R1) x += s1v * (float)L1[st % D][e];
+                    if (R2) x += s2v * (float)L2[st % D][e];
+                    o[e] = (f16)x;
+                }
+            }
+            if (mr < a.M && n + 8 <= a.N) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
+            if (st + D < NP) piece_loads(st + D, st % D);           // refill the ring slot just consumed
+        };
+        char* wr = eb + srow(l31);
+        const int wsw = (l31 >> 1) & 7, wpar = l31 & 1;
+#pragma unroll
+        for (int i = 0; i < MI3; ++i) {
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {                       // the two pairs
+                const int j0 = J0 + 2 * pr;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (f16)(saccv * acc[i][j0 + jj][4 * g + e]);
+                        const int c8 = 8 * jj + 2 * g + lh;
+                        *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = 8 * p + (lane >> 3), blk = lane & 7;
+                    const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                    f16x8 o = v;
+                    if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                    finish(i * PPI + pr * 4 + p, o);
+                }
+            }
+            if constexpr (NJ3 == 5) {                              // the single tile: 32 columns per row
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (f16)(saccv * acc[i][JS][4 * g + e]);
+                    const int c8 = 2 * g + lh;
+                    *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int row = 16 * p + (lane >> 2), blk = lane & 3;
+                    const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                    f16x8 o = v;
+                    if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                    finish(i * PPI + 8 + p, o);
+                }
+            }
+        }
+        wait_lds();
+    };
     // ---- GEGLU pair kind: the weight rows are interleaved in blocks of 16 (weights.interleave_geglu), so accumulator tile j
     //      holds the value columns of outputs 16 j .. 16 j + 15 in registers 0-7 and the matching gate columns in registers
     //      8-15 of the SAME lane: the product is lane-local and a wave's NJ tiles give 16 NJ output columns (80 of the tile's
@@ -593,8 +699,18 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
             if (a.s_acc == 1.0f) epilogue_geglu(IC<1>{}, acc, mw, nw, eb);
             else epilogue_geglu(IC<0>{}, acc, mw, nw, eb);
         } else if constexpr (R1 || R2) {
-            if (RV && idx_u >= 0) epilogue_rows(IC<1>{}, acc, mw, nw, eb);
-            else epilogue_rows(IC<0>{}, acc, mw, nw, eb);
+            if (RV && idx_u < 0) {
+                epilogue_rows(IC<0>{}, acc, mw, nw, eb);           // a per-row vector (tile straddles a frame): fp32 row path
+            } else {                                               // (a uniform row-vector row is already in the accumulators)
+                const bool unit = R1 && !R2 && a.s1 == 1.0f;
+                if (NJ3 == 4 || wn == 0) {
+                    if (unit) epilogue_res16(IC<0>{}, IC<1>{}, acc, mw, nw, eb);
+                    else epilogue_res16(IC<0>{}, IC<0>{}, acc, mw, nw, eb);
+                } else {
+                    if (unit) epilogue_res16(IC<1>{}, IC<1>{}, acc, mw, nw, eb);
+                    else epilogue_res16(IC<1>{}, IC<0>{}, acc, mw, nw, eb);
+                }
+            }
         } else if (RV && idx_u < 0) {
             epilogue_rows(IC<0>{}, acc, mw, nw, eb);
         } else if (NJ3 == 4 || wn == 0) {

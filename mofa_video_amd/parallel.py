@@ -498,11 +498,11 @@ class WindowParallel:
 # ---------------------------------------------------------------------------------------------------------
 # Which layout for a long video (Keypoint window loop) on R ranks?  A pure cost table, no device work.
 # ---------------------------------------------------------------------------------------------------------
-# time of ONE window step on g ranks (2-way CFG x g/2 frame shards) relative to one rank.  ASSUMED until an 8-GPU node has
-# measured them (none has: every SCALE record of this build is a skipped one): g = 2 loses only the CFG pair exchange and the
-# halved tile counts (the single-GPU two-half probe: 252-253 ms against 247.8 for the whole batch, profiles/r03c_stream_variants_probe.log);
-# g = 4 / 8 add the per-rank shapes' lower MFMA rate (profiles/r04_shard_shapes.log) and the exchange groups of the temporal layers.
-WINDOW_STEP_TIME = {1: 1.0, 2: 0.53, 4: 0.29, 8: 0.17}
+# time of ONE window step on g ranks (2-way CFG x g/2 frame shards) relative to one rank: device time per denoise step of rank 0
+# of g on the 1-GPU proxy (tools/shard_proxy.py, loopback transport: no wire time, no waiting for peers -- LOWER bounds of the
+# real times) over 236.3 ms for the whole clip on one GPU: 125.0 / 74.0 / 48.3 ms (profiles/r04_shard_proxy.log).  No multi-GPU
+# node has measured them (every SCALE record of this build is a skipped one); callers with measured times pass ``step_time``.
+WINDOW_STEP_TIME = {1: 1.0, 2: 0.53, 4: 0.31, 8: 0.20}
 
 
 def window_layout_costs(windows, ranks, step_time=None):
