@@ -172,6 +172,11 @@ class FlowControlNetPipeline:
         sample, skips, counts, Hm, Wm = enc
         outs = [None, None]
         side.wait_stream(cur)                                   # the encoder's outputs are ready
+        # Lifetime: the second half READS rows of `sample`, every skip and every residual on `side` while this function's
+        # references may be dropped on `cur` (decode_tokens pops the skip views): tell the allocator about the second reader, so
+        # that none of these blocks can be handed out again before `side` is done with them, whatever decode_tokens keeps alive
+        for tt in [sample, mid] + list(skips) + list(down):
+            tt.record_stream(side)
         for hf, st in enumerate((cur, side)):
             with torch.cuda.stream(st):
                 ch = c_un.halves[hf]
