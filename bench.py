@@ -550,9 +550,10 @@ def main():
         par_desc = {"single": "1 GPU", "replicas": f"{world} independent clips, one per GPU, no data-path collective",
                     "shard": (f"one clip over {world} GPUs, layout from parallel.window_layout_costs: {window_plan}; one all-gather of "
                               "the stepped window latents per round; VAE chunks dealt over all ranks" if cfg == 5 else
-                              f"one clip over {world} GPUs: 2-way CFG x {max(world // 2, 1)}-way frame shards; RCCL "
-                              "all-reduce (temporal GroupNorm sums), halo p2p (temporal convs), all-gather (temporal "
-                              "attention K|V, CFG pair, final latents); VAE chunks round-robin")}[mode]
+                              f"one clip over {world} GPUs: 2-way CFG x {max(world // 2, 1)}-way frame shards; RCCL: per temporal "
+                              "norm + conv one exchange group (raw halo frames p2p + all-gather of the GroupNorm partials), one "
+                              "hidden-token all-gather per temporal attention, CFG pair and final latents all-gathers; trunk || "
+                              "encoder enqueued in lockstep on two streams; VAE chunks round-robin")}[mode]
         line = {
             "metric": (f"denoised frames/sec, 25f 576x1024 SVD+MOFA, {STEPS} steps" if cfg != 5 else
                        f"denoised frames/sec, 97f (4 x 25f windows) 576x1024 SVD+MOFA hybrid, {STEPS} steps") +
@@ -567,7 +568,7 @@ def main():
                        "num_frames": nfr, "height": H, "width": W, "num_inference_steps": STEPS, "backend": args.backend if world > 1 else None,
                        "decode_chunk_size": CHUNK, "step_definition": "one whole clip from the conditioning image (CLIP + VAE "
                        "encode, adapter prep, 25 denoise steps, VAE decode)", "parallelism": par_desc,
-                       "streams": ("single stream" if (args.single_stream or (mode == "shard" and cfg != 5 and world > 2)) else
+                       "streams": ("single stream" if args.single_stream else
                                    "adapter trunk || UNet encoder, then the decoder's two CFG halves, on two HIP streams; the last timed clip (HIP "
                                    "events) single-stream"),
                        "graph_steps": bool(pipe.graph_steps), "clip_ms": clip_ms,
