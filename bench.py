@@ -383,6 +383,8 @@ def main():
     ap.add_argument("--graph-steps", type=int, default=-1, help="A/B switch: pipeline.graph_steps = 0 | 1 (one captured hipGraph per "
                     "clip replayed for steps 1 .. 24; default: the pipeline's)")
     ap.add_argument("--split-decoder", type=int, default=-1, help="A/B switch: pipeline.split_decoder = 0 | 1 (default: the pipeline's)")
+    ap.add_argument("--gn-stats", type=int, default=-1, help="A/B switch: ops.GN_STATS = 0 | 1 (GroupNorm partial sums from the "
+                    "producing implicit-GEMM epilogue; default: on)")
     ap.add_argument("--lib", default="", help="A/B switch: load this build of libmofa_hip.so instead of the in-tree one "
                     "(same-box comparison of two kernel builds; the path is echoed in config.library)")
     args = ap.parse_args()
@@ -458,6 +460,9 @@ def main():
     pipe.overlap_adapter = not args.single_stream
     if args.split_decoder >= 0:
         pipe.split_decoder = bool(args.split_decoder)
+    if args.gn_stats >= 0:
+        from mofa_video_amd import ops as _ops
+        _ops.GN_STATS = bool(args.gn_stats)
     if args.graph_steps >= 0:
         pipe.graph_steps = bool(args.graph_steps)
     for _ in range(args.warmup):
@@ -571,7 +576,8 @@ def main():
                        "streams": ("single stream" if args.single_stream else
                                    "adapter trunk || UNet encoder, then the decoder's two CFG halves, on two HIP streams; the last timed clip (HIP "
                                    "events) single-stream"),
-                       "graph_steps": bool(pipe.graph_steps), "clip_ms": clip_ms,
+                       "graph_steps": bool(pipe.graph_steps), **({"gn_stats": bool(args.gn_stats)} if args.gn_stats >= 0 else {}),
+                       "clip_ms": clip_ms,
                        "output_finite": finite, "comm_paths": comm_paths, **({"library": args.lib} if args.lib else {}),
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},
             "roofline": roofline,

@@ -86,7 +86,15 @@ typedef struct mofa_igemm_args {
                          * of the launch, or NULL.  With it the 256x320 tile splits the tiles of a partial last round of
                          * workgroups along K (fp32 partial tiles here, added in a fixed order by a fix-up launch on the same
                          * stream); without it every tile is computed whole.  Same result up to fp32 summation order.          */
-    int64_t workspace_bytes;   /* 84 MB (256 partial tiles of 256 x 320 fp32) is never exceeded.  sizeof(mofa_igemm_args) = 184 */
+    int64_t workspace_bytes;   /* 84 MB (256 partial tiles of 256 x 320 fp32) is never exceeded.                              */
+    float* stats;       /* optional fp32 [M / 64][N]: for every block of 64 output rows and every PAIR of output columns (2 p, 2 p + 1)
+                         * the sum (element 2 p) and the sum of squares (element 2 p + 1) of the fp16 outputs just written -- the
+                         * GroupNorm partial sums of the layer that follows (diffusers ResnetBlock2D / TemporalResnetBlock: conv ->
+                         * GroupNorm, models/controlnet_sdv.py:270-309), emitted by the producing epilogue so that the consumer does
+                         * not read the activations a third time (mofa_gn_partial_from_stats turns them into `part` entries).
+                         * Only where mofa_igemm_stats_ok() says so (256x320 tile; M % 64 == 0, N % 320 == 0, no activation, at most
+                         * one residual, a row vector that is constant over 64-row blocks); MOFA_EINVAL otherwise.
+                         * sizeof(mofa_igemm_args) = 192 */
 } mofa_igemm_args;
 enum { MOFA_PAD_SAME = 0, MOFA_PAD_TRAILING = 1 };
 /* output tiles of the implicit GEMM: 4 waves / 2 workgroups per CU (128x128, 192x128) and the 8-wave phase-pipelined
@@ -95,6 +103,8 @@ enum { MOFA_PAD_SAME = 0, MOFA_PAD_TRAILING = 1 };
 enum { MOFA_TILE_AUTO = 0, MOFA_TILE_128X128 = 2, MOFA_TILE_192X128 = 4, MOFA_TILE_256X256 = 5, MOFA_TILE_256X320 = 6 };
 
 int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream);
+/* 1 when a launch with these arguments can emit `stats` (the value of a->stats itself is ignored), else 0 */
+int mofa_igemm_stats_ok(const mofa_igemm_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * Attention.  q/k/v are column blocks of token-major matrices: element (token, head, d) at
@@ -149,6 +159,9 @@ int mofa_softmax_rows_f16(void* x, int rows, int cols, int ld, mofa_stream_t str
 /* workspace `part`: fp32 [nframes][nparts][32][2], nparts = mofa_gn_nparts(HW, C) */
 int mofa_gn_nparts(int HW, int C);
 int mofa_gn_partial_f16(const void* x, float* part, int nframes, int HW, int C, int ldx, mofa_stream_t stream);
+/* the same `part` entries from the pair sums an implicit-GEMM epilogue emitted (mofa_igemm_args.stats: fp32 [nframes * HW / 64][C]),
+ * 64-row blocks dealt to the nparts entries of a frame in order, fixed summation order; HW % 64 == 0, (C / 32) even */
+int mofa_gn_partial_from_stats(const float* stats, float* part, int nframes, int HW, int C, mofa_stream_t stream);
 /* frames_per_stat = 1 (spatial) or T (temporal); writes scale/shift fp32 [nframes][C] */
 int mofa_gn_finalize(const float* part, const float* gamma, const float* beta, float* scale, float* shift,
                      int nframes, int HW, int C, int frames_per_stat, float eps, mofa_stream_t stream);

@@ -224,7 +224,9 @@ class SpatioTemporalResBlock:
         alpha = _sigmoid(s.get("time_mixer.mix_factor").reshape(-1)[0])
         self.alpha = (1.0 - alpha) if switch else alpha   # weight of x_spatial
 
-    def __call__(self, x, c, H, W):
+    def __call__(self, x, c, H, W, out_stats=False):
+        """out_stats: the caller's next op on the result is a GroupNorm (a transformer's ``norm`` / the next block's ``norm1``): the last
+        convolution's epilogue emits its partial sums (``ops.igemm(stats=True)``), as the block's inner convolutions always do"""
         HW, N, T = H * W, c.N, c.T
 
         def tvec(lin, off):
@@ -234,22 +236,22 @@ class SpatioTemporalResBlock:
             return dict(rowvec=ops.cast_f16_to_f32(lin(c.temb_act)), rv=(T * HW, 1, 1, BIG))
         h = self.norm1(x, N, HW, silu=True)
         if self.temb is not None:
-            h = self.conv1(h, H, W, **tvec(self.temb, self.temb_off))
+            h = self.conv1(h, H, W, stats=True, **tvec(self.temb, self.temb_off))
         else:
-            h = self.conv1(h, H, W)
+            h = self.conv1(h, H, W, stats=True)
         h = self.norm2(h, N, HW, silu=True)
         xs = self.shortcut(x) if self.shortcut is not None else x
-        xs = self.conv2(h, H, W, r1=xs, s1=1.0)                          # ResnetBlock2D output
         par = c.par
+        xs = self.conv2(h, H, W, r1=xs, s1=1.0, stats=par is None)       # ResnetBlock2D output
         if par is None:
             g = self.tnorm1(xs, N, HW, frames_per_stat=T, silu=True)
             if self.ttemb is not None:
-                g = self.tconv1(g, T, HW, **tvec(self.ttemb, self.ttemb_off))
+                g = self.tconv1(g, T, HW, stats=True, **tvec(self.ttemb, self.ttemb_off))
             else:
-                g = self.tconv1(g, T, HW)
+                g = self.tconv1(g, T, HW, stats=True)
             g = self.tnorm2(g, N, HW, frames_per_stat=T, silu=True)
             # alpha*xs + (1-alpha)*(xs + conv) = xs + (1-alpha)*conv
-            return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0)
+            return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0, stats=out_stats)
         # ---- frames of the clip sharded over ranks (one CFG half per rank; mofa_video_amd/parallel.py) ----
         assert c.B == 1
         g = _sharded_norm_convt3(self.tnorm1, self.tconv1, xs, c, HW,
@@ -372,7 +374,7 @@ class TransformerSpatioTemporal:
             c.cache[key] = (self.attn2(c.ctx16), v_tm, ops.cast_f16_to_f32(e))
         return c.cache[key]
 
-    def __call__(self, x, c, H, W):
+    def __call__(self, x, c, H, W, out_stats=False):
         HW, N, T, B = H * W, c.N, c.T, c.B
         v_sp, v_tm, pos = self._invariants(c)
         h = self.norm(x, N, HW)
@@ -440,7 +442,7 @@ class TransformerSpatioTemporal:
         f = self.tattn1.to_out(a, r1=f, s1=1.0, rowvec=tab, rv=quirk)
         al = self.alpha
         m = self.tff(self.tnorm3(f), s_acc=1.0 - al, r1=f, s1=1.0 - al, r2=h, s2=al)      # AlphaBlender
-        return self.proj_out(m, r1=x, s1=1.0)
+        return self.proj_out(m, r1=x, s1=1.0, stats=out_stats)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -455,10 +457,11 @@ class DownBlock:
         """generator: yields after every res (+ transformer) layer -- the points where ``run_lockstep`` switches to the other
         network of the step; the generator's return value is what ``__call__`` returns"""
         outs = []
+        more = lambda i: i + 1 < len(self.resnets)               # the next layer's norm1 reads this layer's output
         for i, r in enumerate(self.resnets):
-            x = r(x, c, H, W)
+            x = r(x, c, H, W, out_stats=self.attns is not None or more(i))
             if self.attns is not None:
-                x = self.attns[i](x, c, H, W)
+                x = self.attns[i](x, c, H, W, out_stats=more(i))
             outs.append((x, H, W))
             yield
         if self.down is not None:
@@ -478,9 +481,9 @@ class MidBlock:
         self.res1 = SpatioTemporalResBlock(s.sub("resnets.1"), 1e-5)
 
     def layers(self, x, c, H, W):
-        x = self.res0(x, c, H, W)
+        x = self.res0(x, c, H, W, out_stats=True)
         yield
-        x = self.attn(x, c, H, W)
+        x = self.attn(x, c, H, W, out_stats=True)
         yield
         return self.res1(x, c, H, W)
 
@@ -497,7 +500,7 @@ class UpBlock:
     def __call__(self, x, skips, c, H, W):
         for i, r in enumerate(self.resnets):
             x = ops.concat_channels(x, skips.pop())
-            x = r(x, c, H, W)
+            x = r(x, c, H, W, out_stats=self.attns is not None)
             if self.attns is not None:
                 x = self.attns[i](x, c, H, W)
         if self.up is not None:

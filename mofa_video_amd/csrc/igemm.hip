@@ -515,6 +515,10 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     const long long Ktot = (long long)taps * a->Cin;
     const int kind = a->act == MOFA_ACT_GEGLU_PAIR ? 8 : ((a->r1 ? 1 : 0) | (a->r2 ? 2 : 0) | (a->rowvec ? 4 : 0));
     int choice = a->tile;                                     // MOFA_TILE_* or 0 = cost model
+    if (a->stats) {                                           // GroupNorm pair sums from the epilogue: the 256x320 tile only
+        if (!igemm320_stats_ok(a)) return MOFA_EINVAL;
+        choice = MOFA_TILE_256X320;
+    }
     if (choice == 0) {
         // Tile choice = the cheapest of  rounds of resident workgroups x CU time of one round, the latter modelled as
         //   workgroups per CU x tile area x relative K-loop cost per flop x (1 + epilogue / K loop),  epilogue in K tiles:
@@ -569,7 +573,7 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     if (choice == MOFA_TILE_256X320) {
         const int rc = igemm320_launch(a, kind, n_cu, (hipStream_t)stream);
         if (rc <= 0) return rc;                               // launched (0) or failed (< 0)
-        if (a->tile == MOFA_TILE_256X320) return MOFA_EINVAL; // explicitly requested but not eligible
+        if (a->tile == MOFA_TILE_256X320 || a->stats) return MOFA_EINVAL; // explicitly requested but not eligible
         choice = MOFA_TILE_256X256;                           // chosen by the model but not eligible: next best pipeline tile
     }
     if (choice == MOFA_TILE_256X256) {
@@ -590,3 +594,5 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
+
+extern "C" int mofa_igemm_stats_ok(const mofa_igemm_args* a) { return igemm320_stats_ok(a) ? 1 : 0; }

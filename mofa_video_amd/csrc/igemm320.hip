@@ -31,6 +31,9 @@
 
 namespace {
 
+#ifndef STATS_D
+#define STATS_D 5
+#endif
 constexpr int WN3 = 2, MI3 = 2;                                // wave grid 4 x 2, accumulator row tiles per wave
 constexpr int TBM3 = 256;
 constexpr int RBH = 64;                                        // bytes of one K half of a row
@@ -65,7 +68,9 @@ struct Cursor3 {                    // one K-half plane of the persistent K-tile
 // remainder tile aux.tile0 + b / nsplit (see igemm320_launch).  Its accumulators start at zero and leave as an fp32 partial
 // tile in aux.ws; bias, row vector, residuals and activation are applied by igemm320_fixup_kernel.  The item follows the
 // whole tiles in the same persistent stream (the cursors prefetch it during the last whole tile's epilogue).
-template <int EPI, int NJ3, bool SPLIT = false>
+// STATS: the epilogue also emits the GroupNorm pair sums of the outputs (mofa_igemm_args.stats); kinds 0 / 1 / 4 / 5, no
+// activation, no per-row vector (igemm320_stats_ok)
+template <int EPI, int NJ3, bool SPLIT = false, bool STATS = false>
 __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_args a, const int tilesN, const int ntiles,
                                                               const Aux aux) {
     constexpr bool R1 = (EPI & EPI_R1) != 0, R2 = (EPI & EPI_R2) != 0, RV = (EPI & EPI_RV) != 0, GEGLU = (EPI & EPI_GEGLU) != 0;
@@ -169,30 +174,45 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         c.ikc = 0; c.ksw = 0; c.ky = 0; c.kx = 0;
         c.kend = ke;
         if constexpr (SPLIT) {                                     // a slice may start in the middle of a tap
-            const int tap = fdiv(kb, aux.kpt_d);
+            int tap = fdiv(kb, aux.kpt_d);
             c.ikc = kb - tap * kpt;
+#ifdef MOFA_CONV_CHUNK_MAJOR
+            if (a.mode == MOFA_MODE_CONV3X3) { c.ikc = kb / taps; tap = kb - c.ikc * taps; }   // (chunk major: see `issue`)
+#endif
             c.ksw = kb;
             if (a.mode == MOFA_MODE_CONV3X3) { c.ky = fdiv(tap, aux.ks_d); c.kx = tap - c.ky * ks_; } else c.ky = tap;
             c.xo0 = tap_src(c.gx0, c.ky, c.kx, swz_bytes(l, p));
             c.xo1 = tap_src(c.gx1, c.ky, c.kx, swz_bytes(l, p));
         }
     };
+#ifdef MOFA_CONV_CHUNK_MAJOR
+    // EXPERIMENT (r04, verdict item 3d): k x k convolutions walk K CHANNEL CHUNK MAJOR -- for each 64-channel chunk all the taps -- so
+    // that the rows an XCD's 32 tiles share between taps (5 MB over the nine tap passes of the tap-major order at level 0: a 9 x
+    // re-fetch through the fabric) are re-read while they are still in the 4 MB L2 (1 MB per chunk).  Same products, another fp32
+    // summation order.  Cursor: ikc = chunk, (ky, kx) = tap, ksw = position in the stream (ksw = chunk * taps + tap).
+    const bool chunk_major = a.mode == MOFA_MODE_CONV3X3;
+#else
+    constexpr bool chunk_major = false;
+#endif
     auto issue = [&](Cursor3& c, const int p, const int slot) __attribute__((always_inline)) {
-        if (c.ikc == 0) {
+        if (chunk_major || c.ikc == 0) {
             const int l = lane_now();
             c.xo0 = tap_src(c.gx0, c.ky, c.kx, swz_bytes(l, p));
             c.xo1 = tap_src(c.gx1, c.ky, c.kx, swz_bytes(l, p));
         }
         char* pl = smem + slot + p * PLANE;
+        const int wk = chunk_major ? ((c.ky * ks_ + c.kx) * kpt + c.ikc) * 128 : c.ksw * 128;
         bglds16(rsx, c.xo0, c.ikc * 128, pl + wave * 1024);
         bglds16(rsx, c.xo1, c.ikc * 128, pl + (wave + 8) * 1024);
-        bglds16(rsw, c.wo0, c.ksw * 128, pl + XPL + wave * 1024);
-        bglds16(rsw, c.wo0 + wd1, c.ksw * 128, pl + XPL + (wave + 8) * 1024);
-        if (NJ3 == 5 && grp == p) bglds16(rsw, c.wo0 + wd2, c.ksw * 128, pl + XPL + (16 + (wave & 3)) * 1024);
+        bglds16(rsw, c.wo0, wk, pl + XPL + wave * 1024);
+        bglds16(rsw, c.wo0 + wd1, wk, pl + XPL + (wave + 8) * 1024);
+        if (NJ3 == 5 && grp == p) bglds16(rsw, c.wo0 + wd2, wk, pl + XPL + (16 + (wave & 3)) * 1024);
     };
     auto advance = [&](Cursor3& c, const int p) __attribute__((always_inline)) {
         ++c.ksw;
-        if (++c.ikc == kpt) {
+        if (chunk_major) {
+            if (++c.kx == ks_) { c.kx = 0; if (++c.ky == ks_) { c.ky = 0; ++c.ikc; } }
+        } else if (++c.ikc == kpt) {
             c.ikc = 0;
             if (a.mode == MOFA_MODE_CONV3X3) { if (++c.kx == ks_) { c.kx = 0; ++c.ky; } } else ++c.ky;
         }
@@ -462,6 +482,134 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         }
         wait_lds();
     };
+    // ---- STATS kernels: epilogue_res16 (or its residual-free form) with the store pieces walked COLUMN SET by column set -- the
+    //      tile pairs (J0, J0 + 1), (J0 + 2, J0 + 3), then the single tile, each over both row tiles -- so that only one set's
+    //      accumulators (4 column pairs x {sum, sum of squares}) are live at a time (a residual is added in fp16: s1 == 1 only).  A finished piece is 8 consecutive fp16
+    //      outputs of one row: 2 x 4 v_dot2_f32_f16 add the pairs and their squares; after a set, xor-shuffles over the lanes that
+    //      hold the same columns (8 rows each -> the wave's 64 rows), and lanes 0-7 (0-3) write 32 bytes each:
+    //      stats[(m / 64) * N + n .. n + 7] = {s, q} x 4 pairs.  Fixed order: bit-identical run to run. -------------------------
+    auto epilogue_stats = [&](auto wnc, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(wnc)::v ? 1 : 0, JS = decltype(wnc)::v ? 0 : 4;
+        constexpr int NP = 20;                                       // pieces: 2 sets x 2 row tiles x 4, then 2 row tiles x 2
+        const int lane_e = lane_now();
+        const int lane = lane_e, l31 = lane & 31, lh = lane >> 5;
+        f16* out = (f16*)a.out;
+        const f16* r1 = (const f16*)a.r1;
+        float saccv = a.s_acc;
+        asm volatile("" : "+v"(saccv));
+        auto piece_pos = [&](int st, int& mr, int& n) __attribute__((always_inline)) {
+            if (st < 16) {                                           // set st / 8, row tile (st / 4) % 2, piece st % 4
+                mr = mw + 32 * ((st >> 2) & 1) + 8 * (st & 3) + (lane >> 3);
+                n = nw + 32 * (J0 + 2 * (st >> 3)) + 8 * (lane & 7);
+            } else {                                                 // the single tile: row tile (st - 16) / 2, piece (st - 16) % 2
+                mr = mw + 32 * ((st - 16) >> 1) + 16 * ((st - 16) & 1) + (lane >> 2);
+                n = nw + 32 * JS + 8 * (lane & 3);
+            }
+        };
+        constexpr int D = STATS_D;
+        f16x8 L1[D];
+        auto piece_loads = [&](int st, int slot) __attribute__((always_inline)) {
+            int mr, n;
+            piece_pos(st, mr, n);
+            mr = mr < a.M ? mr : a.M - 1;
+            L1[slot] = *(const f16x8*)(r1 + (size_t)mr * a.ldr1 + n);
+        };
+        if constexpr (R1) {
+#pragma unroll
+            for (int st = 0; st < D; ++st) piece_loads(st, st);
+        }
+        float S[4], Q[4];
+        const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+        auto finish = [&](int st, f16x8 o) __attribute__((always_inline)) {
+            int mr, n;
+            piece_pos(st, mr, n);
+            if constexpr (R1) o = o + L1[st % D];                   // (s1 == 1: the residual add in fp16, as the reference's modules)
+            if (mr < a.M) *(f16x8*)(out + (size_t)mr * a.ldo + n) = o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f16x2 h = {o[2 * k], o[2 * k + 1]};
+                S[k] = __builtin_amdgcn_fdot2(h, one2, S[k], false);
+                Q[k] = __builtin_amdgcn_fdot2(h, h, Q[k], false);
+            }
+            // (pins the eight v_dot2 HERE: left alone the compiler sinks them to the end of the column set and keeps all eight
+            // pieces' outputs -- 32 registers -- live until then, which spills)
+            asm volatile("" : "+v"(S[0]), "+v"(S[1]), "+v"(S[2]), "+v"(S[3]), "+v"(Q[0]), "+v"(Q[1]), "+v"(Q[2]), "+v"(Q[3]));
+            if constexpr (R1) {
+                if (st + D < NP) piece_loads(st + D, st % D);       // refill the ring slot just consumed
+            }
+        };
+        auto reduce_store = [&](const int from, const int n0, const bool writer) __attribute__((always_inline)) {
+            // (ds_bpermute addressed from the laundered lane id: __shfl_xor's own lane id is loop invariant, gets hoisted out of the
+            // tile loop and then lives -- spilled -- across the K loop)
+#pragma unroll
+            for (int o = from; o < 64; o <<= 1) {
+                const int src = (lane ^ o) << 2;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    S[k] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, S[k])));
+                    Q[k] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, Q[k])));
+                }
+            }
+            if (writer && mw < a.M) {                                // (M % 64 == 0: the wave's 64 rows are all inside or all outside)
+                float* sp = a.stats + (size_t)(mw >> 6) * a.N + n0;
+                *(f32x4*)sp = (f32x4){S[0], Q[0], S[1], Q[1]};
+                *(f32x4*)(sp + 4) = (f32x4){S[2], Q[2], S[3], Q[3]};
+            }
+        };
+        char* wr = eb + srow(l31);
+        const int wsw = (l31 >> 1) & 7, wpar = l31 & 1;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {                           // the two pairs
+            const int j0 = J0 + 2 * pr;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { S[k] = 0.f; Q[k] = 0.f; }
+#pragma unroll
+            for (int i = 0; i < MI3; ++i) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (f16)(saccv * acc[i][j0 + jj][4 * g + e]);
+                        const int c8 = 8 * jj + 2 * g + lh;
+                        *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+                    }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = 8 * p + (lane >> 3), blk = lane & 7;
+                    const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                    f16x8 o = v;
+                    if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                    finish(pr * 8 + i * 4 + p, o);
+                }
+            }
+            reduce_store(8, nw + 32 * j0 + 8 * (lane & 7), lane < 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { S[k] = 0.f; Q[k] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < MI3; ++i) {                            // the single tile: 32 columns per row
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (f16)(saccv * acc[i][JS][4 * g + e]);
+                const int c8 = 2 * g + lh;
+                *(f16x4*)(wr + (((c8 >> 1) ^ wsw) << 4) + (((c8 & 1) ^ wpar) << 3)) = o;
+            }
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int row = 16 * p + (lane >> 2), blk = lane & 3;
+                const f16x8 v = *(const f16x8*)(eb + srow(row) + ((blk ^ ((row >> 1) & 7)) << 4));
+                f16x8 o = v;
+                if (row & 1) o = (f16x8){v[4], v[5], v[6], v[7], v[0], v[1], v[2], v[3]};
+                finish(16 + i * 2 + p, o);
+            }
+        }
+        reduce_store(4, nw + 32 * JS + 8 * (lane & 3), lane < 4);
+        wait_lds();
+    };
     // ---- GEGLU pair kind: the weight rows are interleaved in blocks of 16 (weights.interleave_geglu), so accumulator tile j
     //      holds the value columns of outputs 16 j .. 16 j + 15 in registers 0-7 and the matching gate columns in registers
     //      8-15 of the SAME lane: the product is lane-local and a wave's NJ tiles give 16 NJ output columns (80 of the tile's
@@ -695,6 +843,9 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         char* eb = smem + ((gt - 1) & 1) * SLOT + PLANE + wave * 1024;
         if (SPLIT && cph == 1) {
             epilogue_dump(acc, aux.ws + (size_t)blockIdx.x * (TBM3 * TBN3), eb);
+        } else if constexpr (STATS) {                              // (kinds 0 / 1 / 4 / 5; the launcher excluded a per-row vector and s1 != 1)
+            if (wn == 0) epilogue_stats(IC<0>{}, acc, mw, nw, eb);
+            else epilogue_stats(IC<1>{}, acc, mw, nw, eb);
         } else if constexpr (GEGLU) {
             if (a.s_acc == 1.0f) epilogue_geglu(IC<1>{}, acc, mw, nw, eb);
             else epilogue_geglu(IC<0>{}, acc, mw, nw, eb);
@@ -787,6 +938,29 @@ __global__ __launch_bounds__(256) void igemm320_fixup_kernel(const mofa_igemm_ar
     }
 }
 
+// STATS launches with a split-K last round: the remainder tiles get their outputs from the fix-up kernel, so their pair sums are
+// taken from the finished outputs (R tiles x 4 row blocks; a few MB, L2 / MALL resident): one workgroup per (tile, 64-row block),
+// one thread per column pair, rows in order
+__global__ __launch_bounds__(192) void igemm320_tile_stats_kernel(const f16* __restrict__ out, const int ldo, float* __restrict__ stats,
+                                                                  const int M, const int N, const int tile0, const int tilesN) {
+    constexpr int TBN = Geo<5>::TBN;
+    const int tile = tile0 + (int)(blockIdx.x >> 2), tm = tile / tilesN, tn = tile - tm * tilesN;
+    const int m0 = tm * TBM3 + 64 * (int)(blockIdx.x & 3), n = tn * TBN + 2 * (int)threadIdx.x;
+    if (m0 >= M || (int)threadIdx.x >= TBN / 2 || n + 2 > N) return;
+    const f16x2 one2 = {(f16)1.0f, (f16)1.0f};
+    float sm = 0.f, q = 0.f;
+    const f16* p = out + (size_t)m0 * ldo + n;
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) {
+        const f16x2 h = *(const f16x2*)(p + (size_t)r * ldo);
+        sm = __builtin_amdgcn_fdot2(h, one2, sm, false);
+        q = __builtin_amdgcn_fdot2(h, h, q, false);
+    }
+    float* sp = stats + (size_t)(m0 >> 6) * N + n;
+    sp[0] = sm;
+    sp[1] = q;
+}
+
 }  // namespace
 
 // (kind 7 = row vector + two residuals does not fit the register file beside 160 accumulators and occurs nowhere in the
@@ -798,6 +972,13 @@ static const igemm320_kern_t k_igemm320_split[7] = {
     igemm320_f16_kernel<0, 5, true>, igemm320_f16_kernel<1, 5, true>, igemm320_f16_kernel<2, 5, true>, igemm320_f16_kernel<3, 5, true>,
     igemm320_f16_kernel<4, 5, true>, igemm320_f16_kernel<5, 5, true>, igemm320_f16_kernel<6, 5, true>};
 
+// STATS instantiations (GroupNorm pair sums from the epilogue): the kinds the networks' GroupNorm producers use -- plain (down-sampling
+// conv), one residual (conv2 / the temporal conv2 / proj_out), uniform row vector (conv1 + time embedding), both
+static const igemm320_kern_t k_igemm320_stats[7] = {igemm320_f16_kernel<0, 5, false, true>, igemm320_f16_kernel<1, 5, false, true>, nullptr,
+                                                     nullptr, igemm320_f16_kernel<4, 5, false, true>, igemm320_f16_kernel<5, 5, false, true>, nullptr};
+static const igemm320_kern_t k_igemm320_split_stats[7] = {igemm320_f16_kernel<0, 5, true, true>, igemm320_f16_kernel<1, 5, true, true>, nullptr,
+                                                           nullptr, igemm320_f16_kernel<4, 5, true, true>, igemm320_f16_kernel<5, 5, true, true>, nullptr};
+
 int igemm320_init() {
     for (igemm320_kern_t k : k_igemm320)
         if (k && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
@@ -805,7 +986,25 @@ int igemm320_init() {
     for (igemm320_kern_t k : k_igemm320_split)
         if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
             return MOFA_ELAUNCH;
+    for (int i = 0; i < 7; ++i)
+        for (igemm320_kern_t k : {k_igemm320_stats[i], k_igemm320_split_stats[i]})
+            if (k && hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Geo<5>::LDS_BYTES) != hipSuccess)
+                return MOFA_ELAUNCH;
     return MOFA_OK;
+}
+
+// can a launch with these arguments emit mofa_igemm_args.stats?  (a->stats itself is not looked at)
+bool igemm320_stats_ok(const mofa_igemm_args* a) {
+    if (!a || !a->x || !a->w || !a->out || a->M <= 0 || a->N <= 0 || a->Cin <= 0 || a->Cin % 64 != 0) return false;
+    if (a->act != MOFA_ACT_NONE || a->r2 || (a->r1 && a->s1 != 1.0f)) return false;
+    if (a->M % 64 != 0 || a->N % Geo<5>::TBN != 0) return false;
+    if (a->rowvec && (a->rv_mod_in != 1 || a->rv_div <= 0 || a->rv_div % 64 != 0)) return false;   // constant over a wave's 64 rows
+    if (a->tile != 0 && a->tile != MOFA_TILE_256X320) return false;
+    const int taps = a->mode == MOFA_MODE_CONV3X3 ? (a->ksize > 0 ? a->ksize * a->ksize : 9) : (a->mode == MOFA_MODE_CONVT3 ? 3 : 1);
+    const int kind = (a->r1 ? 1 : 0) | (a->rowvec ? 4 : 0);
+    if (!igemm_pipe_eligible(a, kind, (long long)taps * a->Cin)) return false;
+    if ((long long)(a->N + Geo<5>::TBN) * taps * a->Cin * 2 >= 0x7ff00000LL) return false;
+    return true;
 }
 
 // Split-K for the tiles of a partial last round.  T tiles on n_cu persistent workgroups take ceil(T / n_cu) tile times although
@@ -844,10 +1043,12 @@ int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t st
     const int nk = taps * (a->Cin / 64);
     const bool ws_ok = a->workspace && (((size_t)a->workspace) & 15) == 0;
     const int S = kind == 8 ? 1 : igemm320_split(nt, nk, n_cu, ws_ok ? a->workspace_bytes : 0);   // (the fix-up has no GEGLU form)
+    if (a->stats && (kind > 6 || !k_igemm320_stats[kind] || (((size_t)a->stats) & 15) || !igemm320_stats_ok(a))) return MOFA_EINVAL;
     if (S == 1) {
         int grid = (int)(nt < n_cu ? ((nt + 7) / 8) * 8 : (n_cu / 8) * 8);
         if (grid < 8) grid = 8;
-        hipLaunchKernelGGL(k_igemm320[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a, tilesN, (int)nt, aux);
+        hipLaunchKernelGGL(a->stats ? k_igemm320_stats[kind] : k_igemm320[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a, tilesN,
+                           (int)nt, aux);
         MOFA_CHECK_LAUNCH();
         return MOFA_OK;
     }
@@ -861,11 +1062,17 @@ int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t st
     aux.ws = (float*)a->workspace;
     int grid = full > 0 ? (n_cu / 8) * 8 : ((items + 7) / 8) * 8;
     if (grid < items) return MOFA_EINVAL;                       // (R * S <= n_cu by construction)
-    hipLaunchKernelGGL(k_igemm320_split[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a, tilesN, (int)full, aux);
+    hipLaunchKernelGGL(a->stats ? k_igemm320_split_stats[kind] : k_igemm320_split[kind], dim3(grid), dim3(512), Geo<5>::LDS_BYTES, stream, *a,
+                       tilesN, (int)full, aux);
     MOFA_CHECK_LAUNCH();
     const long long pieces = (long long)R * TBM3 * (tbn / 8);
     hipLaunchKernelGGL(igemm320_fixup_kernel, dim3((int)((pieces + 255) / 256)), dim3(256), 0, stream, *a,
                        (const float*)a->workspace, (int)full, S, tilesN, R);
     MOFA_CHECK_LAUNCH();
+    if (a->stats) {                                              // the remainder tiles' pair sums, from their finished outputs
+        hipLaunchKernelGGL(igemm320_tile_stats_kernel, dim3(R * 4), dim3(192), 0, stream, (const f16*)a->out, a->ldo, a->stats, a->M,
+                           a->N, (int)full, tilesN);
+        MOFA_CHECK_LAUNCH();
+    }
     return MOFA_OK;
 }

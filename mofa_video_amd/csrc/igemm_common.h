@@ -104,4 +104,5 @@ int igemm8_init();
 // igemm320.hip: the 256x320 tile (same return convention: 0 launched, < 0 error, 1 not eligible)
 int igemm320_launch(const mofa_igemm_args* a, int kind, int n_cu, hipStream_t stream);
 int igemm320_init();
+bool igemm320_stats_ok(const mofa_igemm_args* a);             // mofa_igemm_args.stats can be emitted for these arguments
 int igemm320_split(long long tiles, int nk, int n_cu, long long ws_bytes);   // K slices for the remainder tiles (1 = none)

@@ -115,6 +115,48 @@ extern "C" int mofa_gn_partial_f16(const void* x, float* part, int nframes, int 
     return MOFA_OK;
 }
 
+// `part` entries from the pair sums an implicit-GEMM epilogue emitted (mofa_igemm_args.stats: fp32 [frames * HW / 64][C], element 2 p =
+// sum, 2 p + 1 = sum of squares of columns 2 p, 2 p + 1 over a block of 64 rows): grid = (nparts, frames); the HW / 64 row blocks of
+// a frame are dealt to its nparts entries in order; thread (group g, sub-lane u) adds pairs u, u + 8, .. of its group over the
+// entry's blocks in block order, then one thread per group adds the 8 sub-lanes in order: deterministic.
+__global__ __launch_bounds__(256) void gn_from_stats_kernel(const float* __restrict__ st, float* __restrict__ part, int HW, int C,
+                                                            int nparts) {
+    __shared__ float sS[8][32], sQ[8][32];
+    const int tid = threadIdx.x, sub = tid & 7, g = tid >> 3;
+    const int e = blockIdx.x, frame = blockIdx.y;
+    const int nb = HW >> 6;
+    const int b0 = (int)(((long long)e * nb) / nparts), b1 = (int)(((long long)(e + 1) * nb) / nparts);
+    const int cpg = C / 32, ppg = cpg >> 1;
+    float s = 0.f, q = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const float* row = st + ((size_t)frame * nb + b) * C + g * cpg;
+        for (int j = sub; j < ppg; j += 8) {
+            const float2 v = *(const float2*)(row + 2 * j);
+            s += v.x;
+            q += v.y;
+        }
+    }
+    sS[sub][g] = s;
+    sQ[sub][g] = q;
+    __syncthreads();
+    if (tid < 32) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { a += sS[r][tid]; b += sQ[r][tid]; }
+        float* p = part + (((size_t)frame * nparts + e) * 32 + tid) * 2;
+        p[0] = a;
+        p[1] = b;
+    }
+}
+
+extern "C" int mofa_gn_partial_from_stats(const float* stats, float* part, int nframes, int HW, int C, mofa_stream_t stream) {
+    if (!stats || !part || nframes <= 0 || HW <= 0 || HW % 64 != 0 || C <= 0 || C % 64 != 0 || C > 4096) return MOFA_EINVAL;
+    const int nch = gn_nchunks(HW);
+    hipLaunchKernelGGL(gn_from_stats_kernel, dim3(nch, nframes), dim3(256), 0, (hipStream_t)stream, stats, part, HW, C, nch);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ scale,
                                                           float* __restrict__ shift, int HW, int C, int fps, int nparts,

@@ -35,6 +35,7 @@ class IgemmArgs(C.Structure):
         ("s_acc", C.c_float), ("s1", C.c_float), ("s2", C.c_float),
         ("dil", C.c_int32), ("pad", C.c_int32), ("tile", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+        ("stats", C.c_void_p),
     ]
 
 
@@ -43,7 +44,8 @@ _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 # name -> argtypes (every symbol include/mofa_hip.h declares; tests check they all resolve)
 PROTOTYPES = {
     "mofa_version": [],
-    "mofa_igemm_f16": [_P, _P],                     # (const mofa_igemm_args*: a byref(IgemmArgs) or the packed 184 bytes)
+    "mofa_igemm_f16": [_P, _P],                     # (const mofa_igemm_args*: a byref(IgemmArgs) or the packed 192 bytes)
+    "mofa_igemm_stats_ok": [_P],
     "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_attn_spatial_qb_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],
@@ -52,6 +54,7 @@ PROTOTYPES = {
     "mofa_softmax_rows_f16": [_P, _I, _I, _I, _P],
     "mofa_gn_nparts": [_I, _I],
     "mofa_gn_partial_f16": [_P, _P, _I, _I, _I, _I, _P],
+    "mofa_gn_partial_from_stats": [_P, _P, _I, _I, _I, _P],
     "mofa_gn_finalize": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
     "mofa_gn_reduce": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_gn_finalize_sums": [_P, _P, _P, _P, _P, _I, _I, _I, C.c_double, _F, _P],

@@ -130,18 +130,24 @@ def igemm_workspace(device):
     return ws
 
 
-# mofa_igemm_args (include/mofa_hip.h, 184 bytes) packed in one call: the ~40 ctypes field stores of a Structure cost more
+# mofa_igemm_args (include/mofa_hip.h, 192 bytes) packed in one call: the ~40 ctypes field stores of a Structure cost more
 # host time than everything else in this wrapper, and the host's time per launch is what bounds a frame-sharded rank
-_IGEMM_ARGS = struct.Struct("@7P22i3f3iPq")
+_IGEMM_ARGS = struct.Struct("@7P22i3f3iPqP")
 assert _IGEMM_ARGS.size == C.sizeof(L.IgemmArgs)
 _TAPS_FIXED = {L.MODE_PLAIN: 1, L.MODE_CONVT3: 3}
 
 
+GN_STATS = True          # A/B switch: False = every GroupNorm takes its partial sums with mofa_gn_partial_f16 (three passes)
+
+
 def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, r2=None, s2=1.0,
-          act=L.ACT_NONE, s_acc=1.0, out=None, tile=None, split_k=True):
+          act=L.ACT_NONE, s_acc=1.0, out=None, tile=None, split_k=True, stats=False):
     """out[m,n] = act(s_acc*(conv/gemm + bias + rowvec[idx(m)]) + s1*r1 + s2*r2).  See include/mofa_hip.h.
     tile: one of lib.TILE_* to force the output tile (parity tests); default = ops.FORCE_TILE = the launcher's model.
-    split_k: hand the launcher this stream's scratch buffer so that it may split a partial last round of tiles along K."""
+    split_k: hand the launcher this stream's scratch buffer so that it may split a partial last round of tiles along K.
+    stats: the caller's next op on the result is a GroupNorm: where the launch can (``mofa_igemm_stats_ok``) its epilogue also emits
+    the pair sums of the outputs (``mofa_igemm_args.stats``); they travel as the attribute ``gn_stats`` of the FRESH output tensor
+    (never of a caller-supplied ``out``) and ``group_norm`` consumes them instead of reading the activations for its partial sums."""
     lib = L.load()
     assert x.is_cuda and x.dtype is F16 and w.dtype is F16 and w.is_contiguous() and x.stride(1) == 1, "fp16 cuda, unit channel stride"
     N, Ktot = w.shape
@@ -157,7 +163,8 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
         else:
             M = x.shape[0]
     n_out = N // 2 if act == L.ACT_GEGLU_PAIR else N
-    if out is None:
+    fresh = out is None
+    if fresh:
         out = torch.empty((M, n_out), dtype=F16, device=x.device)
     else:
         assert out.dtype is F16 and out.is_cuda and out.shape[0] == M and out.shape[1] >= n_out and out.stride(1) == 1
@@ -183,11 +190,19 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
         pw, nw = ws.data_ptr(), ws.numel()
     else:
         pw = nw = 0
-    args = _IGEMM_ARGS.pack(x.data_ptr(), w.data_ptr(), pb, pv, p1, p2, out.data_ptr(),
-                            M, N, Cin, x.stride(0), out.stride(0), ld1, ld2, mode,
-                            geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up, geom.ksize, geom.T, geom.HW,
-                            rv[0], rv[1], rv[2], rv[3], act, s_acc, s1, s2, geom.dil, geom.pad,
-                            FORCE_TILE if tile is None else tile, pw, nw)
+    tile_ = FORCE_TILE if tile is None else tile
+    st = None
+    if stats and GN_STATS and fresh and M % 64 == 0 and N % 320 == 0 and act == L.ACT_NONE and r2 is None and (r1 is None or s1 == 1.0):
+        st = torch.empty((M // 64, N), dtype=F32, device=x.device)
+    while True:
+        args = _IGEMM_ARGS.pack(x.data_ptr(), w.data_ptr(), pb, pv, p1, p2, out.data_ptr(),
+                                M, N, Cin, x.stride(0), out.stride(0), ld1, ld2, mode,
+                                geom.Hin, geom.Win, geom.Hout, geom.Wout, geom.stride, geom.up, geom.ksize, geom.T, geom.HW,
+                                rv[0], rv[1], rv[2], rv[3], act, s_acc, s1, s2, geom.dil, geom.pad,
+                                tile_, pw, nw, st.data_ptr() if st is not None else 0)
+        if st is None or lib.mofa_igemm_stats_ok(args) == 1:
+            break
+        st = None                                             # (alignment / geometry the 256x320 tile does not take: plain launch)
     t0 = TIMER.start() if TIMER is not None else None
     if split_k:
         with _igemm_ws_lock:
@@ -199,6 +214,8 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
     if t0 is not None:
         TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot,
                    tag=(mode, geom.stride, geom.up, M, N, Ktot, act))
+    if st is not None:
+        out.gn_stats = st
     return out
 
 
@@ -214,7 +231,12 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
     nparts = lib.mofa_gn_nparts(HW, Cc)
     part = torch.empty((nframes, nparts, 32, 2), dtype=F32, device=x.device)
     st = L.stream_ptr()
-    L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part), nframes, HW, Cc, _ld(x), st), "mofa_gn_partial_f16")
+    pairs = getattr(x, "gn_stats", None)                      # pair sums the producing igemm epilogue emitted (igemm(stats=True))
+    if pairs is not None and HW % 64 == 0 and Cc % 64 == 0 and tuple(pairs.shape) == (nframes * HW // 64, Cc) == (x.shape[0] // 64, x.shape[1]):
+        L.check(lib.mofa_gn_partial_from_stats(L.ptr(pairs), L.ptr(part), nframes, HW, Cc, st), "mofa_gn_partial_from_stats")
+        del x.gn_stats                                            # one shot: they describe x as the producer left it
+    else:
+        L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part), nframes, HW, Cc, _ld(x), st), "mofa_gn_partial_f16")
     if out is None:
         out = torch.empty((x.shape[0], Cc), dtype=F16, device=x.device)
     if frames_per_stat * nparts <= GN_FUSED_MAX_ENTRIES:

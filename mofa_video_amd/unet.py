@@ -107,7 +107,7 @@ class UNetSpatioTemporalConditionControlNetModel:
 
     def encode_layers(self, x, c, H, W):
         """conv_in + down blocks + mid block as a layer generator (blocks.run_lockstep); returns what ``encode_tokens`` returns"""
-        sample = self.conv_in(x, H, W)
+        sample = self.conv_in(x, H, W, stats=True)                   # (the first resnet's norm1 reads it next)
         skips = [sample]
         counts = []
         for blk in self.down_blocks:

@@ -12,7 +12,7 @@ F16, F32 = torch.float16, torch.float32
 
 
 def igemm(x, w, bias=None, geom=None, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, r2=None, s2=1.0,
-          act=L.ACT_NONE, s_acc=1.0, out=None):
+          act=L.ACT_NONE, s_acc=1.0, out=None, stats=False):
     from mofa_video_amd import ops
     geom = geom or ops.PLAIN
     N, Ktot = w.shape

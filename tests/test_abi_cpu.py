@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_igemm_args_struct_layout_matches_header():
     from mofa_video_amd.lib import IgemmArgs
-    # 7 pointers + 22 int32 + 3 float + 3 int32 (dil, pad, tile) = 56 + 88 + 12 + 12 = 168, + workspace pointer + int64 size
-    assert ctypes.sizeof(IgemmArgs) == 184 and IgemmArgs.workspace.offset == 168
+    # 7 pointers + 22 int32 + 3 float + 3 int32 (dil, pad, tile) = 56 + 88 + 12 + 12 = 168, + workspace pointer + int64 size + stats pointer
+    assert ctypes.sizeof(IgemmArgs) == 192 and IgemmArgs.workspace.offset == 168 and IgemmArgs.stats.offset == 184
     assert IgemmArgs.M.offset == 56 and IgemmArgs.ksize.offset == 112 and IgemmArgs.s_acc.offset == 144
 
 

@@ -1,0 +1,168 @@
+"""GroupNorm partial sums emitted by the implicit-GEMM epilogue (``mofa_igemm_args.stats``, 256x320 tile) against the sums of
+the outputs themselves, and the GroupNorm that consumes them against the three-pass form and an fp32 PyTorch reference.
+
+Reference chain: conv -> GroupNorm -> SiLU -> conv in diffusers ResnetBlock2D / TemporalResnetBlock as the reference builds them
+(MOFA-Video-Traj/models/controlnet_sdv.py:270-309, models/unet_spatio_temporal_condition_controlnet.py:169-232).
+
+Stated bars: the outputs of a stats launch are BIT-IDENTICAL to the same launch without stats on the same tile; a pair sum is the
+fp32 sum of 128 fp16 values (|err| <= 1e-5 * sum |x| + 1e-6 * sum x^2 resp.); the GroupNorm built on them is within the kernel
+tolerance of the fp32 reference and within 2e-3 (one fp16 step) of the three-pass GroupNorm (different fp32 summation order of the same numbers).
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+T320 = 6
+
+
+def _h(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, generator=g, device=DEV) * scale).half()
+
+
+def _f(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator(device=DEV).manual_seed(seed), device=DEV)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mofa_video_amd import lib
+    from mofa_video_amd import ops as o
+    lib.load()
+    return o
+
+
+def _pair_sums(out):
+    """fp64 reference of the stats layout: [M / 64][N], element 2 p = sum, 2 p + 1 = sum of squares of columns 2 p, 2 p + 1"""
+    M, N = out.shape
+    o = out.double().reshape(M // 64, 64, N // 2, 2)
+    s, q = o.sum(dim=(1, 3)), (o * o).sum(dim=(1, 3))
+    return torch.stack([s, q], dim=-1).reshape(M // 64, N), o.abs().sum(dim=(1, 3))
+
+
+def _check_stats(st, out, what):
+    ref, mag = _pair_sums(out)
+    assert tuple(st.shape) == tuple(ref.shape), (st.shape, ref.shape)
+    d = (st.double() - ref).abs().reshape(ref.shape[0], -1, 2)
+    r = ref.reshape(ref.shape[0], -1, 2)
+    bad_s = d[..., 0] > 1e-5 * mag + 1e-4
+    bad_q = d[..., 1] > 1e-5 * r[..., 1] + 1e-4
+    assert not bad_s.any() and not bad_q.any(), (f"{what}: {int(bad_s.sum())} sums / {int(bad_q.sum())} square sums off; max "
+                                                  f"{d[..., 0].max().item():.3e} / {d[..., 1].max().item():.3e}")
+
+
+# (mode, geometry, N, Cin, kind); M chosen so that the launch spans > 1 round of 256 tiles with a split-K remainder where noted
+CASES = [
+    ("gemm", 64 * 45, 320, 320, "bias"),                       # 12 tiles, last one 64 rows: whole blocks in / out
+    ("gemm", 64 * 45, 640, 128, "r1"),
+    ("gemm", 256 * 260, 320, 2560, "r1"),                      # 260 tiles: one full round + 4 remainder tiles split 5-way along K
+    ("gemm", 256 * 258, 320, 2560, "rvu"),                     # remainder tiles (fix-up + tile-stats kernels) + uniform row vector
+    ("conv", (6, 24, 32), 320, 64, "rvu"),
+    ("conv", (6, 24, 32), 640, 128, "r1"),
+    ("conv_s2", (5, 32, 48), 320, 64, "bias"),                 # down-sampling conv: 16 x 24 outputs per image
+    ("convt", (2, 5, 576), 320, 128, "r1rvu"),
+    ("convt", (1, 8, 2304), 1280, 64, "r1"),
+]
+
+
+@pytest.mark.parametrize("mode,geo,N,Cin,kind", CASES)
+def test_igemm_stats_vs_outputs(ops, mode, geo, N, Cin, kind):
+    from mofa_video_amd import lib as L
+    if mode == "gemm":
+        M, geom, taps = geo, ops.PLAIN, 1
+        x = _h(M, Cin, seed=1)
+    elif mode in ("conv", "conv_s2"):
+        n, H, W = geo
+        geom = ops.conv3x3_geom(H, W, stride=2 if mode == "conv_s2" else 1)
+        M, taps = n * geom.Hout * geom.Wout, 9
+        x = _h(n * H * W, Cin, seed=1)
+    else:
+        b, T, HW = geo
+        M, geom, taps = b * T * HW, ops.convt3_geom(T, HW), 3
+        x = _h(M, Cin, seed=1)
+    assert M % 64 == 0
+    w = _h(N, taps * Cin, seed=2, scale=(taps * Cin) ** -0.5)
+    bias = _f(N, seed=3)
+    kw = dict(s_acc=0.75)
+    if "r1" in kind:
+        kw.update(r1=_h(M, N, seed=4), s1=1.0)
+    if "rvu" in kind:
+        blk = 64 * 9
+        kw.update(rowvec=_f(5, N, seed=5), rv=(blk, 3, 1, 5))
+    plain = ops.igemm(x, w, bias, geom=geom, M=M, tile=T320, **kw)
+    out = ops.igemm(x, w, bias, geom=geom, M=M, stats=True, **kw)
+    st = getattr(out, "gn_stats", None)
+    assert st is not None, "the launch was expected to take the stats path"
+    assert torch.equal(out, plain), f"outputs differ from the plain 256x320 launch: {(out.float() - plain.float()).abs().max().item():.3e}"
+    _check_stats(st, out, f"{mode} {kind}")
+    out2 = ops.igemm(x, w, bias, geom=geom, M=M, stats=True, **kw)          # deterministic
+    assert torch.equal(out2.gn_stats, st) and torch.equal(out2, out)
+    # kinds the stats kernels do not take run as plain launches without the attribute
+    o3 = ops.igemm(x, w, bias, geom=geom, M=M, stats=True, act=L.ACT_SILU)
+    assert getattr(o3, "gn_stats", None) is None
+    if "r1" in kind:
+        o4 = ops.igemm(x, w, bias, geom=geom, M=M, stats=True, r1=kw["r1"], s1=0.5)
+        assert getattr(o4, "gn_stats", None) is None
+
+
+@pytest.mark.parametrize("C,HW,frames,fps", [(320, 576, 6, 1), (320, 2304, 4, 4), (640, 576, 10, 5), (1280, 576, 4, 2), (320, 9216, 2, 1)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_group_norm_from_stats(ops, C, HW, frames, fps, silu):
+    M, Cin = frames * HW, 64
+    x = _h(M, Cin, seed=11)
+    w = _h(C, Cin, seed=12, scale=0.2)
+    bias = _f(C, seed=13)
+    g, b = _f(C, seed=14), _f(C, seed=15)
+    y = ops.igemm(x, w, bias, stats=True)
+    assert getattr(y, "gn_stats", None) is not None
+    y_plain = y.clone()                                          # (no attribute: the three-pass GroupNorm)
+    fused = ops.group_norm(y, g, b, frames, HW, 1e-5, frames_per_stat=fps, silu=silu)
+    assert getattr(y, "gn_stats", None) is None, "the pair sums are consumed once"
+    three = ops.group_norm(y_plain, g, b, frames, HW, 1e-5, frames_per_stat=fps, silu=silu)
+    yr = y_plain.float().reshape(frames // fps, fps * HW, C).transpose(1, 2)
+    ref = F.group_norm(yr, 32, g, b, eps=1e-5)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.transpose(1, 2).reshape(M, C)
+    scale = ref.abs().max().item()
+    err = (fused.float() - ref).abs()
+    assert (err <= 2e-3 * scale + 2e-3 * ref.abs()).all(), f"fused GroupNorm vs fp32 reference: {err.max().item():.3e} (scale {scale:.3e})"
+    d = (fused.float() - three.float()).abs().max().item()
+    assert d <= 2e-3 * scale + 2e-3, f"fused vs three-pass GroupNorm: {d:.3e}"
+    fused2 = ops.group_norm(ops.igemm(x, w, bias, stats=True), g, b, frames, HW, 1e-5, frames_per_stat=fps, silu=silu)
+    assert torch.equal(fused, fused2), "not deterministic"
+
+
+def test_resblock_stats_switch(ops):
+    """a SpatioTemporalResBlock + transformer norm with the epilogue-emitted sums against the same layers with ops.GN_STATS off"""
+    from mofa_video_amd import blocks
+    torch.manual_seed(5)
+    C, T, H, W = 320, 4, 24, 24
+    sd = {}
+    for pre, taps in (("spatial_res_block.conv1", (3, 3)), ("spatial_res_block.conv2", (3, 3))):
+        sd[pre + ".weight"] = (torch.randn(C, C, *taps) * (C * 9) ** -0.5).half()
+        sd[pre + ".bias"] = (torch.randn(C) * 0.1).half()
+    for pre in ("temporal_res_block.conv1", "temporal_res_block.conv2"):
+        sd[pre + ".weight"] = (torch.randn(C, C, 3, 1, 1) * (C * 3) ** -0.5).half()
+        sd[pre + ".bias"] = (torch.randn(C) * 0.1).half()
+    for pre in ("spatial_res_block.norm1", "spatial_res_block.norm2", "temporal_res_block.norm1", "temporal_res_block.norm2"):
+        sd[pre + ".weight"] = (1 + 0.1 * torch.randn(C)).half()
+        sd[pre + ".bias"] = (0.1 * torch.randn(C)).half()
+    sd["time_mixer.mix_factor"] = torch.tensor([0.3])
+    blk = blocks.SpatioTemporalResBlock(blocks.Sub(sd, "", DEV), 1e-6)
+    c = blocks.Ctx(1, T)
+    x = _h(T * H * W, C, seed=21)
+    outs = []
+    for on in (True, False):
+        ops.GN_STATS = on
+        try:
+            y = blk(x, c, H, W, out_stats=True)
+            assert (getattr(y, "gn_stats", None) is not None) == on
+            outs.append(y.clone())
+        finally:
+            ops.GN_STATS = True
+    d = (outs[0].float() - outs[1].float()).abs().max().item()
+    scale = outs[1].float().abs().max().item()
+    assert d <= 2e-3 * scale, f"res block with / without epilogue statistics: {d:.3e} (scale {scale:.3e})"

@@ -18,7 +18,7 @@ from mofa_video_amd import lib, ops  # noqa: E402
 
 DEV = "cuda"
 TILES = [("128", lib.TILE_128X128), ("192", lib.TILE_192X128), ("256p", lib.TILE_256X256), ("320p", lib.TILE_256X320),
-         ("auto", lib.TILE_AUTO)]
+         ("auto", lib.TILE_AUTO), ("320s", -1)]
 
 # (mode, M-or-(n,H,W), N, Cin, epilogue, launches per denoise step [UNet + ControlNet], tag)
 SHAPES = [
@@ -82,8 +82,17 @@ def make_call(mode, Mg, N, Cin, epi):
             kw.update(r1=h(M, N), s1=1.0)
         elif epi == "rv":
             kw.update(rowvec=torch.randn(64, N, device=DEV), rv=(max(M // 50, 1), 1, 1, 64))
+    kw_s = dict(kw)                                          # "320s": the 256x320 tile emitting GroupNorm pair sums (fresh output)
     kw.update(out=out)
-    return (lambda tile: ops.igemm(x, w, bias, tile=tile, **kw)), 2.0 * M * N * K
+
+    def call(tile):
+        if tile == -1:
+            y = ops.igemm(x, w, bias, tile=lib.TILE_256X320, stats=True, **kw_s)
+            if getattr(y, "gn_stats", None) is None:
+                raise lib.MofaHipError("no stats path for this shape")
+            return y
+        return ops.igemm(x, w, bias, tile=tile, **kw)
+    return call, 2.0 * M * N * K
 
 
 def main():
