@@ -215,6 +215,10 @@ int mofa_subsample_tokens_f16(const void* x, void* y, int n, int H, int W, int s
                               mofa_stream_t stream);
 /* y[m][c] = a * x[m][c] + b * y[m][c]  (fp16 storage, fp32 math); C % 8 == 0 */
 int mofa_axpby_f16(const void* x, void* y, int M, int C, int ldx, int ldy, float a, float b, mofa_stream_t stream);
+/* out[m][c] = a * x[m][c] + b * y[m][c], written elsewhere (x, y untouched): the UNet's skip + ControlNet residual sum goes
+ * straight into its column slice of the decoder's concat buffer (unet_spatio_temporal_condition_controlnet.py:447-459, :478-483) */
+int mofa_axpby_out_f16(const void* x, const void* y, void* out, int M, int C, int ldx, int ldy, int ldo, float a, float b,
+                       mofa_stream_t stream);
 /* out[m][j] = x[m][j] * gelu(x[m][Ch + j]), j < Ch  (diffusers GEGLU, erf gelu) */
 int mofa_geglu_f16(const void* x, void* out, int M, int Ch, int ldx, int ldo, mofa_stream_t stream);
 /* strided 2-D copy of a column block: dst[m][0..C) = src[m][0..C); C % 8 == 0 */
@@ -246,6 +250,12 @@ int mofa_softsplat_avg_f16(const void* feat, const float* flow, void* out, void*
                            int nflows, int H, int W, int C, int ldf, int ldo, mofa_stream_t stream);
 int mofa_softsplat_scatter_f32(const float* in, const float* flow, float* out_sum, int N, int C, int H, int W,
                                mofa_stream_t stream);
+/* the wrapper's metric-weighted modes (models/softsplat.py:243-270; not on the inference path): 'linear' (mode 1) / 'soft' (mode 2)
+ * build [in * w | w], w = metric / exp(metric), fp32 [N][C+1][H][W]; after mofa_softsplat_scatter_f32 of that, the normalisation
+ * divides by the splatted last channel: eps_mode 0 '+1e-7' ('' / 'addeps'), 1 'zeroeps', 2 'clipeps', 3 unchanged */
+int mofa_softsplat_weight_f32(const float* in, const float* metric, float* out, int N, int C, int H, int W, int mode,
+                              mofa_stream_t stream);
+int mofa_softsplat_normalize_f32(const float* summed, float* out, int N, int C, int H, int W, int eps_mode, mofa_stream_t stream);
 /* F.interpolate(flow, scale_factor=1/s) (nearest) / s  (svdxt_..._norefine.py:302-309): fp32 [n][2][H][W] -> [n][2][H/s][W/s] */
 int mofa_flow_downscale_f32(const float* flow, float* out, int n, int H, int W, int s, mofa_stream_t stream);
 

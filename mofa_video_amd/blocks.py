@@ -224,9 +224,10 @@ class SpatioTemporalResBlock:
         alpha = _sigmoid(s.get("time_mixer.mix_factor").reshape(-1)[0])
         self.alpha = (1.0 - alpha) if switch else alpha   # weight of x_spatial
 
-    def __call__(self, x, c, H, W, out_stats=False):
+    def __call__(self, x, c, H, W, out_stats=False, out=None):
         """out_stats: the caller's next op on the result is a GroupNorm (a transformer's ``norm`` / the next block's ``norm1``): the last
-        convolution's epilogue emits its partial sums (``ops.igemm(stats=True)``), as the block's inner convolutions always do"""
+        convolution's epilogue emits its partial sums (``ops.igemm(stats=True)``), as the block's inner convolutions always do.
+        out: where the block's result goes (a column slice of the decoder's next concat buffer) instead of a fresh tensor"""
         HW, N, T = H * W, c.N, c.T
 
         def tvec(lin, off):
@@ -251,15 +252,15 @@ class SpatioTemporalResBlock:
                 g = self.tconv1(g, T, HW, stats=True)
             g = self.tnorm2(g, N, HW, frames_per_stat=T, silu=True)
             # alpha*xs + (1-alpha)*(xs + conv) = xs + (1-alpha)*conv
-            return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0, stats=out_stats)
+            return self.tconv2(g, T, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0, stats=out_stats, out=out)
         # ---- frames of the clip sharded over ranks (one CFG half per rank; mofa_video_amd/parallel.py) ----
         assert c.B == 1
         g = _sharded_norm_convt3(self.tnorm1, self.tconv1, xs, c, HW,
                                  **(tvec(self.ttemb, self.ttemb_off) if self.ttemb is not None else {}))
-        return _sharded_norm_convt3(self.tnorm2, self.tconv2, g, c, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0)
+        return _sharded_norm_convt3(self.tnorm2, self.tconv2, g, c, HW, s_acc=1.0 - self.alpha, r1=xs, s1=1.0, out=out)
 
 
-def _sharded_norm_convt3(norm, conv, x, c, HW, r1=None, **epi):
+def _sharded_norm_convt3(norm, conv, x, c, HW, r1=None, out=None, **epi):
     """GroupNorm over the WHOLE clip (+ SiLU) -> (3,1,1) convolution, on the T = c.T frames of the clip this rank holds.
     One exchange group (parallel.FrameParallel): the raw boundary frames of x leave for the neighbour shards at once; the
     GroupNorm partials are all-gathered (the only wait of the compute stream) and every rank combines them itself; the own
@@ -276,7 +277,8 @@ def _sharded_norm_convt3(norm, conv, x, c, HW, r1=None, **epi):
     cnt = float(par.T_full) * HW * (Cc // 32)
     ext = torch.empty(((T + 2) * HW, Cc), dtype=x.dtype, device=x.device)
     ops.gn_apply_gathered(x, buf, cnt, norm.g, norm.b, norm.eps, ext[HW:(T + 1) * HW], T, HW, silu=True)
-    out = torch.empty((M, conv.w.shape[0]), dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty((M, conv.w.shape[0]), dtype=x.dtype, device=x.device)
     geom = ops.convt3_geom(0, HW)                                   # unclipped: the halo rows lie before / after a.x
 
     def launch(f0, f1):
@@ -374,7 +376,7 @@ class TransformerSpatioTemporal:
             c.cache[key] = (self.attn2(c.ctx16), v_tm, ops.cast_f16_to_f32(e))
         return c.cache[key]
 
-    def __call__(self, x, c, H, W, out_stats=False):
+    def __call__(self, x, c, H, W, out_stats=False, out=None):
         HW, N, T, B = H * W, c.N, c.T, c.B
         v_sp, v_tm, pos = self._invariants(c)
         h = self.norm(x, N, HW)
@@ -442,7 +444,7 @@ class TransformerSpatioTemporal:
         f = self.tattn1.to_out(a, r1=f, s1=1.0, rowvec=tab, rv=quirk)
         al = self.alpha
         m = self.tff(self.tnorm3(f), s_acc=1.0 - al, r1=f, s1=1.0 - al, r2=h, s2=al)      # AlphaBlender
-        return self.proj_out(m, r1=x, s1=1.0, stats=out_stats)
+        return self.proj_out(m, r1=x, s1=1.0, stats=out_stats, out=out)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -497,16 +499,44 @@ class UpBlock:
         self.attns = [TransformerSpatioTemporal(s.sub(f"attentions.{i}"), heads) for i in range(num_layers)] if cross else None
         self.up = Conv3x3(s.sub("upsamplers.0.conv"), up=2) if upsample else None
 
-    def __call__(self, x, skips, c, H, W):
+    def __call__(self, cat, skips, c, H, W):
+        """cat: fp16 [rows, Cx + Cs] whose first Cx columns already hold the block's input -- its producer wrote them in place
+        (``concat_target``); skips: list of (skip, ControlNet residual or None, multiplicity), consumed from the end.  The skip +
+        multiplicity x residual sum of the reference (unet_..._controlnet.py:447-459) goes straight into the other Cs columns,
+        and every layer writes its result into the columns of the NEXT concat buffer: no copy of either operand of a
+        ``torch.cat`` (:478-483 of the reference's up-block loop in diffusers).  Returns that next buffer (or, when no skip is
+        left, the plain result), H, W."""
+        x = cat
         for i, r in enumerate(self.resnets):
-            x = ops.concat_channels(x, skips.pop())
-            x = r(x, c, H, W, out_stats=self.attns is not None)
+            sk, res, m = skips.pop()
+            Cx = cat.shape[1] - sk.shape[1]
+            if res is not None and m:
+                ops.axpby_out(res, sk, float(m), 1.0, out=cat[:, Cx:])
+            else:
+                ops.copy2d(sk, cat[:, Cx:])
+            direct = i + 1 < len(self.resnets) or self.up is None    # this layer's result is the next concat's first operand
+            nxt, tgt = concat_target(cat.shape[0], r.tconv2.w.shape[0], skips, cat) if direct else (None, None)
+            x = r(cat, c, H, W, out_stats=self.attns is not None, out=tgt if self.attns is None else None)
             if self.attns is not None:
-                x = self.attns[i](x, c, H, W)
+                x = self.attns[i](x, c, H, W, out=tgt)
+            if nxt is not None:
+                cat = x = nxt
         if self.up is not None:
-            x = self.up(x, H, W)
+            nxt, tgt = concat_target(cat.shape[0] * 4, self.up.w.shape[0], skips, cat)
+            x = self.up(x, H, W, out=tgt)
             H, W = H * 2, W * 2
+            if nxt is not None:
+                x = nxt
         return x, H, W
+
+
+def concat_target(rows, Cx, skips, like):
+    """the buffer of the NEXT channel concat -- [rows, Cx + width of the skip on top of ``skips``] -- and its first Cx columns,
+    which the producer of the concat's first operand writes in place; (None, None) when no skip is left"""
+    if not skips:
+        return None, None
+    nxt = torch.empty((rows, Cx + skips[-1][0].shape[1]), dtype=like.dtype, device=like.device)
+    return nxt, nxt[:, :Cx]
 
 
 class TimeEmbedding:

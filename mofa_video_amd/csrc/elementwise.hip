@@ -29,6 +29,30 @@ extern "C" int mofa_axpby_f16(const void* x, void* y, int M, int C, int ldx, int
     return MOFA_OK;
 }
 
+// out = a*x + b*y (the same arithmetic, written elsewhere: a column slice of a concat buffer)
+__global__ __launch_bounds__(256) void axpby_out_kernel(const f16* __restrict__ x, const f16* __restrict__ y, f16* __restrict__ out,
+                                                        long long nvec, int CV, int ldx, int ldy, int ldo, float a, float b) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long long)gridDim.x * 256) {
+        const long long row = i / CV;
+        const int cv = (int)(i - row * CV);
+        const f16x8 xv = *(const f16x8*)(x + (size_t)row * ldx + cv * 8);
+        const f16x8 yv = *(const f16x8*)(y + (size_t)row * ldy + cv * 8);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)(a * (float)xv[e] + b * (float)yv[e]);
+        *(f16x8*)(out + (size_t)row * ldo + cv * 8) = o;
+    }
+}
+extern "C" int mofa_axpby_out_f16(const void* x, const void* y, void* out, int M, int C, int ldx, int ldy, int ldo, float a, float b,
+                                  mofa_stream_t stream) {
+    if (!x || !y || !out || M <= 0 || C <= 0 || C % 8 != 0 || ldx % 8 != 0 || ldy % 8 != 0 || ldo % 8 != 0) return MOFA_EINVAL;
+    const long long nvec = (long long)M * (C / 8);
+    hipLaunchKernelGGL(axpby_out_kernel, dim3(ew_blocks(nvec)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)y,
+                       (f16*)out, nvec, C / 8, ldx, ldy, ldo, a, b);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
 // out[m][j] = x[m][j] * gelu(x[m][Ch + j])
 __global__ __launch_bounds__(256) void geglu_kernel(const f16* __restrict__ x, f16* __restrict__ out, long long nvec, int CV,
                                                     int Ch, int ldx, int ldo) {

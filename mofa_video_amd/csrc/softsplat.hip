@@ -251,3 +251,53 @@ extern "C" int mofa_softsplat_scatter_f32(const float* in, const float* flow, fl
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
+
+// ---- the metric-weighted modes of the reference wrapper (Traj/models/softsplat.py:243-270), off the inference path: 'linear' /
+//      'soft' splat [in * w | w] with w = metric / exp(metric) and divide by the splatted last channel ------------------------------
+__global__ __launch_bounds__(256) void splat_weight_kernel(const float* __restrict__ in, const float* __restrict__ metric,
+                                                           float* __restrict__ out, int C, long long HW, long long total, int mode) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW, r = i / HW;               // r = n * (C + 1) + c
+        const int c = (int)(r % (C + 1));
+        const long long n = r / (C + 1);
+        float w = metric[n * HW + p];
+        if (mode == 2) w = expf(w);
+        out[i] = c < C ? in[(n * C + c) * HW + p] * w : w;
+    }
+}
+extern "C" int mofa_softsplat_weight_f32(const float* in, const float* metric, float* out, int N, int C, int H, int W, int mode,
+                                         mofa_stream_t stream) {
+    if (!in || !metric || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || (mode != 1 && mode != 2)) return MOFA_EINVAL;
+    const long long HW = (long long)H * W, total = (long long)N * (C + 1) * HW;
+    long long nb = (total + 255) / 256;
+    nb = nb > 16384 ? 16384 : nb;
+    hipLaunchKernelGGL(splat_weight_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, in, metric, out, C, HW, total, mode);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}
+
+// out[n][c] = summed[n][c] / norm(summed[n][C]); eps_mode 0: + 1e-7 ('' / 'addeps'), 1: 0 -> 1 ('zeroeps'), 2: max(., 1e-7)
+// ('clipeps'), 3: as it is (any other suffix: the reference leaves the channel untouched)
+__global__ __launch_bounds__(256) void splat_normalize_kernel(const float* __restrict__ summed, float* __restrict__ out, int C,
+                                                              long long HW, long long total, int eps_mode) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i % HW, r = i / HW;               // r = n * C + c
+        const int c = (int)(r % C);
+        const long long n = r / C;
+        float d = summed[(n * (C + 1) + C) * HW + p];
+        if (eps_mode == 0) d = d + 0.0000001f;
+        else if (eps_mode == 1) d = d == 0.0f ? 1.0f : d;
+        else if (eps_mode == 2) d = fmaxf(d, 0.0000001f);
+        out[i] = summed[(n * (C + 1) + c) * HW + p] / d;
+    }
+}
+extern "C" int mofa_softsplat_normalize_f32(const float* summed, float* out, int N, int C, int H, int W, int eps_mode,
+                                            mofa_stream_t stream) {
+    if (!summed || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0 || eps_mode < 0 || eps_mode > 3) return MOFA_EINVAL;
+    const long long HW = (long long)H * W, total = (long long)N * C * HW;
+    long long nb = (total + 255) / 256;
+    nb = nb > 16384 ? 16384 : nb;
+    hipLaunchKernelGGL(splat_normalize_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, summed, out, C, HW, total, eps_mode);
+    MOFA_CHECK_LAUNCH();
+    return MOFA_OK;
+}

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "mofa_matting_blend_f16": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_subsample_tokens_f16": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "mofa_axpby_f16": [_P, _P, _I, _I, _I, _I, _F, _F, _P],
+    "mofa_axpby_out_f16": [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _P],
     "mofa_geglu_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_copy2d_f16": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_silu_f32": [_P, _P, _I, _P],
@@ -79,6 +80,8 @@ PROTOTYPES = {
     "mofa_softsplat_ws_bytes": [_I, _I, _I],
     "mofa_softsplat_avg_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "mofa_softsplat_scatter_f32": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "mofa_softsplat_weight_f32": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "mofa_softsplat_normalize_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "mofa_flow_downscale_f32": [_P, _P, _I, _I, _I, _I, _P],
     "mofa_prepare_model_input": [_P, _P, _P, _I, _I, _I, _F, _P],
     "mofa_cfg_euler_step": [_P, _P, _I, _I, _I, _F, _F, _F, _F, _P],

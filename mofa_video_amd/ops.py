@@ -357,6 +357,15 @@ def axpby_(x, y, a=1.0, b=1.0):
     return y
 
 
+def axpby_out(x, y, a, b, out):
+    """out = a*x + b*y (x, y untouched; out may be a column slice of a wider buffer)"""
+    lib = L.load()
+    assert x.shape == y.shape == out.shape
+    L.check(lib.mofa_axpby_out_f16(L.ptr(x), L.ptr(y), L.ptr(out), x.shape[0], x.shape[1], _ld(x), _ld(y), _ld(out), a, b,
+                                   L.stream_ptr()), "mofa_axpby_out_f16")
+    return out
+
+
 def axpby_f32_(x, y, a=1.0, b=1.0):
     """y = a*x + b*y on contiguous fp32 tensors of equal size (in place on y)"""
     lib = L.load()
@@ -519,6 +528,29 @@ def softsplat_scatter_f32(tenIn, tenFlow):
     out = torch.zeros_like(tenIn)
     L.check(lib.mofa_softsplat_scatter_f32(L.ptr(tenIn.contiguous()), L.ptr(tenFlow.contiguous()), L.ptr(out), N, Cc, H,
                                            W, L.stream_ptr()), "mofa_softsplat_scatter_f32")
+    return out
+
+
+def softsplat_weight_f32(tenIn, tenMetric, mode):
+    """[in * w | w], w = metric (mode 1, 'linear') or exp(metric) (mode 2, 'soft'): fp32 [N, C + 1, H, W]"""
+    lib = L.load()
+    _chk(tenIn, F32); _chk(tenMetric, F32)
+    N, Cc, H, W = tenIn.shape
+    assert tuple(tenMetric.shape) == (N, 1, H, W)
+    out = torch.empty((N, Cc + 1, H, W), dtype=F32, device=tenIn.device)
+    L.check(lib.mofa_softsplat_weight_f32(L.ptr(tenIn.contiguous()), L.ptr(tenMetric.contiguous()), L.ptr(out), N, Cc, H, W, mode,
+                                          L.stream_ptr()), "mofa_softsplat_weight_f32")
+    return out
+
+
+def softsplat_normalize_f32(summed, eps_mode):
+    """summed fp32 [N, C + 1, H, W] -> [N, C, H, W] = summed[:, :C] / norm(summed[:, C:])"""
+    lib = L.load()
+    _chk(summed, F32)
+    N, C1, H, W = summed.shape
+    out = torch.empty((N, C1 - 1, H, W), dtype=F32, device=summed.device)
+    L.check(lib.mofa_softsplat_normalize_f32(L.ptr(summed.contiguous()), L.ptr(out), N, C1 - 1, H, W, eps_mode, L.stream_ptr()),
+            "mofa_softsplat_normalize_f32")
     return out
 
 

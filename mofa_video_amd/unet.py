@@ -125,14 +125,18 @@ class UNetSpatioTemporalConditionControlNetModel:
 
     def decode_tokens(self, enc, c, down_res, mid_res):
         sample, skips, counts, H, W = enc
-        ops.axpby_(mid_res, sample, 1.0, 1.0)
-        # residual quirk, applied after the mid block has consumed the last (un-added) skip
+        # residual quirk, applied after the mid block has consumed the last (un-added) skip: skip i + multiplicity x residual i.
+        # Nothing is added in place and nothing is copied for the channel concats: the sums are written straight into their
+        # columns of the concat buffers by the up blocks (blocks.UpBlock), the encoder's tensors stay as they are.
         mult = residual_multiplicity(counts, len(down_res))
-        for sk, r, m in zip(skips, down_res, mult):
-            if m:
-                ops.axpby_(r, sk, float(m), 1.0)
+        assert len(skips) == len(down_res)
+        lazy = list(zip(skips, down_res, mult))
+        from .blocks import concat_target
+        cat, tgt = concat_target(sample.shape[0], sample.shape[1], lazy, sample)
+        ops.axpby_out(mid_res, sample, 1.0, 1.0, out=tgt)            # mid block output + mid residual -> first concat operand
+        sample = cat
         for blk in self.up_blocks:
-            sample, H, W = blk(sample, skips, c, H, W)
+            sample, H, W = blk(sample, lazy, c, H, W)
         sample = self.conv_norm_out(sample, c.N, H * W, silu=True)
         return self.conv_out(sample, H, W)
 

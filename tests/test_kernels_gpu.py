@@ -365,6 +365,27 @@ def test_softsplat_scatter_vs_oracle(ops):
     _close(out, softsplat_sum(x, flow), tol=1e-5, what="softsplat scatter")
 
 
+@pytest.mark.parametrize("mode", ["linear", "soft", "linear-zeroeps", "soft-clipeps", "soft-addeps", "avg-zeroeps", "avg", "sum"])
+def test_softsplat_modes_vs_oracle(mode):
+    """the reference wrapper's strMode surface (Traj/models/softsplat.py:232-274) through mofa_video_amd.softsplat, vs the oracle"""
+    from mofa_video_amd.softsplat import softsplat as splat
+    from oracle.softsplat import softsplat as splat_ref
+    N, C, H, W = 2, 8, 12, 20
+    g = torch.Generator().manual_seed(52)
+    x = torch.randn(N, C, H, W, generator=g)
+    if mode == "avg":
+        x = x.half().float()                      # (the 'avg' path works on fp16 features)
+    if mode == "avg-zeroeps":
+        x = x.abs() + 0.1                         # (reference quirk: 'avg-<suffix>' normalises by the input's own last channel)
+    metric = torch.randn(N, 1, H, W, generator=g) if mode.split("-")[0] in ("linear", "soft") else None
+    if mode.startswith("linear"):
+        metric = metric.abs() + 0.1               # a positive importance metric, as the mode is meant for
+    flow = _flows(N, H, W, 53, 2.0)
+    out = splat(x.to(DEV), flow.to(DEV), metric.to(DEV) if metric is not None else None, mode)
+    ref = splat_ref(x, flow, metric, mode)
+    _close(out, ref, tol=1.5e-3 if mode == "avg" else 2e-5, what=f"softsplat {mode}")
+
+
 def test_scheduler_kernels_vs_oracle(ops):
     from oracle.scheduler import EulerDiscreteScheduler
     T, h, w = 5, 6, 8
