@@ -14,7 +14,7 @@ def rows(name):
 
 
 def total(rs, counter, col="counter_sum"):
-    return sum(float(r[col]) for r in rs if "igemm" in r["kernel"] and "fixup" not in r["kernel"] and r["counter"] == counter)
+    return sum(float(r[col]) for r in rs if "igemm" in r["kernel"] and "fixup" not in r["kernel"] and "tile_stats" not in r["kernel"] and r["counter"] == counter)
 
 
 f, w, m = rows("FETCH_SIZE"), rows("WRITE_SIZE"), rows("mfma")
