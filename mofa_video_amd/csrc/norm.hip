@@ -407,6 +407,29 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     }
 }
 
+// rows per workgroup of gn_apply: ONE round of resident workgroups -- (workgroups that fit the chip) / frames chunks per frame, at
+// least 16 rows each.  (Until r04b: about 64 K elements per workgroup, which at level 0 made 2 250 workgroups for 2 048 slots: a
+// second round one tenth full, 4.5 TB/s where the same kernel streams 5.2 TB/s on 4 500 or 1 150 workgroups.)
+static int gn_apply_rows_per_wg(int HW, int C, int nframes, int total_entries) {
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0, nb = 0;
+        if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+              cus > 0))
+            cus = 256;
+        // (4 KB of dynamic LDS: the occupancy of this kernel is bound by its 8 waves per SIMD, not by C * 8 bytes of LDS, up to C = 1280)
+        if (!(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gn_apply_kernel, 256, 4096) == hipSuccess && nb > 0)) nb = 8;
+        slots = cus * nb;
+    }
+    int chunks = slots / nframes;
+    chunks = chunks < 1 ? 1 : chunks;
+    int rpw = cdiv(HW, chunks);
+    // (a floor of total_entries * 256 / C rows, so that a workgroup's re-read of its set's partial entries stays below a quarter of its
+    // own bytes, was measured too: level-1 temporal norms 56 -> 70 us with 750 workgroups; the entries come from L2, the rows do not)
+    (void)C; (void)total_entries;
+    return rpw < 16 ? 16 : rpw;
+}
+
 extern "C" int mofa_gn_apply_f16(const void* x, const float* part, const float* gamma, const float* beta, void* y, int nframes,
                                  int HW, int C, int ldx, int ldy, int frames_per_stat, float eps, int silu,
                                  mofa_stream_t stream) {
@@ -414,9 +437,7 @@ extern "C" int mofa_gn_apply_f16(const void* x, const float* part, const float* 
         nframes % frames_per_stat != 0 || C % 32 != 0 || C % 8 != 0 || C > 4096 || ldx % 8 != 0 || ldy % 8 != 0)
         return MOFA_EINVAL;                                  // C <= 4096 as mofa_gn_partial_f16 (C * 8 B of dynamic + 8.5 KB static LDS)
     const int nparts = mofa_gn_nparts(HW, C);
-    // rows per workgroup: about 64 K elements each (16 vectors of 8 per thread), at least 2 workgroups per CU in total
-    int rpw = (65536 + C - 1) / C;
-    while (rpw > 16 && (long long)cdiv(HW, rpw) * nframes < 1024) rpw = (rpw + 1) / 2;
+    const int rpw = gn_apply_rows_per_wg(HW, C, nframes, frames_per_stat * nparts);
     const int chunks = cdiv(HW, rpw);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(chunks, nframes), dim3(256), (size_t)C * 8, (hipStream_t)stream, (const f16*)x, part,
                        gamma, beta, (f16*)y, HW, C, ldx, ldy, frames_per_stat, frames_per_stat * nparts,
@@ -436,6 +457,7 @@ extern "C" int mofa_gn_apply_gathered_f16(const void* x, const float* part_all, 
     if (!x || !part_all || !gamma || !beta || !y || nframes <= 0 || HW <= 0 || nentries <= 0 || nentries > 4096 ||
         count_per_group <= 0 || C % 32 != 0 || C % 8 != 0 || C > 4096 || ldx % 8 != 0 || ldy % 8 != 0)
         return MOFA_EINVAL;
+    // (a rank's few frames against the whole clip's gathered entries: about 64 K elements per workgroup, at least 1 024 workgroups)
     int rpw = (65536 + C - 1) / C;
     while (rpw > 16 && (long long)cdiv(HW, rpw) * nframes < 1024) rpw = (rpw + 1) / 2;
     const int chunks = cdiv(HW, rpw);
@@ -445,102 +467,152 @@ extern "C" int mofa_gn_apply_gathered_f16(const void* x, const float* part_all, 
     return MOFA_OK;
 }
 
-// LayerNorm: 16 lanes per token row (4 rows per wave, 16 per workgroup pass), the row held in registers (C <= 1280);
-// reductions are 4 xor-shuffles inside the 16-lane group.  gamma / beta are staged in LDS once per workgroup and a 16-lane
-// group walks LN_ROWS rows (r03): loading them from memory per row was 4 x the row's own load instructions (12 x 16 B of L1-resident parameters
-// against 3 x 16 B of data at C = 320) and bound the kernel on the CU's texture path at 3.6 TB/s.
+// LayerNorm: LPR lanes per token row (16, or 8 where C / 8 = 40 vectors divide evenly by 8 but not by 16: C = 320, the level-0
+// width -- with 16 lanes the third vector of a row kept half the lanes idle), the row held in registers (C <= 1280); reductions
+// are xor-shuffles inside the lane group.  gamma / beta are staged in LDS once per workgroup (r03: loading them per row was 4 x the
+// row's own load instructions and bound the kernel on the CU's texture path at 3.6 TB/s).  r04b: the row stays PACKED (fp16, 4
+// registers per vector instead of 8) unless a row vector is added first -- C = 1280 went from 160 to under 100 VGPRs, 3 -> 5 waves
+// per SIMD --, and a workgroup walks `nrr` consecutive passes of 256 / LPR rows chosen by the launcher so that the grid is ONE round of
+// resident workgroups (3 600 workgroups on 1 792 slots = 1.76 rounds left the second round 3/4 empty at level 0).
 #define LN_MAXIT 10
-#define LN_ROWS 8
-template <int MAXIT>
+template <int MAXIT, int LPR, bool RV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, f16* __restrict__ y, int M,
                                                         int C, int ldx, int ldy, float eps,
-                                                        const float* __restrict__ rowvec, int rv_div, int rv_mod) {
-    __shared__ __attribute__((aligned(16))) float sG[16 * 8 * MAXIT], sB[16 * 8 * MAXIT];
-    const int l16 = threadIdx.x & 15;
+                                                        const float* __restrict__ rowvec, int rv_div, int rv_mod, int nrr) {
+    __shared__ __attribute__((aligned(16))) float sG[LPR * 8 * MAXIT], sB[LPR * 8 * MAXIT];
+    constexpr int GROUPS = 256 / LPR;                              // rows per pass
+    const int lg = threadIdx.x & (LPR - 1);
     const int CV = C >> 3;
     for (int c = threadIdx.x; c < C; c += 256) { sG[c] = gamma[c]; sB[c] = beta[c]; }
     __syncthreads();
     const float inv_c = 1.0f / (float)C;
-    const int row0 = (blockIdx.x * LN_ROWS) * 16 + (threadIdx.x >> 4);
+    const int row0 = (int)blockIdx.x * nrr * GROUPS + (int)(threadIdx.x / LPR);
 #pragma unroll 1
-    for (int rr = 0; rr < LN_ROWS; ++rr) {
-        const int row = row0 + rr * 16;
+    for (int rr = 0; rr < nrr; ++rr) {
+        const int row = row0 + rr * GROUPS;
         if (row >= M) break;
-        float v[MAXIT][8];
         const f16* xp = x + (size_t)row * ldx;
-        const float* rv = rowvec ? rowvec + (size_t)((row / rv_div) % rv_mod) * C : nullptr;
-        float sum = 0.f;
+        f16x8 a[MAXIT];
+        float v[RV ? MAXIT : 1][8];                                // (row vector kinds: x + rowvec in fp32, as the reference adds it)
+        const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int cv = l16 + 16 * it;
-            if (cv < CV) {
-                const f16x8 a = *(const f16x8*)(xp + cv * 8);
-                f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
-                if (rv) { r0 = *(const f32x4*)(rv + cv * 8); r1 = *(const f32x4*)(rv + cv * 8 + 4); }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = (float)a[e] + (e < 4 ? r0[e] : r1[e - 4]);
-                    v[it][e] = t;
-                    sum += t;
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
-            }
+            const int cv = lg + LPR * it;
+            a[it] = cv < CV ? *(const f16x8*)(xp + cv * 8) : zero8;
         }
+        float sum = 0.f;
+        if constexpr (RV) {
+            const float* rv = rowvec + (size_t)((row / rv_div) % rv_mod) * C;
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            for (int it = 0; it < MAXIT; ++it) {
+                const int cv = lg + LPR * it;
+                if (cv < CV) {
+                    const f32x4 r0 = *(const f32x4*)(rv + cv * 8), r1 = *(const f32x4*)(rv + cv * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = (float)a[it][e] + (e < 4 ? r0[e] : r1[e - 4]);
+                        v[it][e] = t;
+                        sum += t;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += (float)a[it][e];     // (vectors beyond C are zero)
+        }
+        auto val = [&](int it, int e) __attribute__((always_inline)) -> float {
+            if constexpr (RV) return v[it][e];
+            else return (float)a[it][e];
+        };
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
         const float mean = sum * inv_c;
+        if constexpr (!RV) {                                       // keep the row PACKED between the passes: without this hipcc converts it
+#pragma unroll                                                     // once and holds 8 fp32 registers per vector instead of 4
+            for (int it = 0; it < MAXIT; ++it) asm volatile("" : "+v"(a[it]));
+        }
         float sq = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int cv = l16 + 16 * it;
+            const int cv = lg + LPR * it;
             if (cv < CV) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float d = v[it][e] - mean;
+                    const float d = val(it, e) - mean;
                     sq = fmaf(d, d, sq);
                 }
             }
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+        for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
         const float rstd = rsqrtf(sq * inv_c + eps);
+        if constexpr (!RV) {
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) asm volatile("" : "+v"(a[it]));
+        }
         f16* yp = y + (size_t)row * ldy;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int cv = l16 + 16 * it;
+            const int cv = lg + LPR * it;
             if (cv < CV) {
                 const f32x4 g0 = *(const f32x4*)(sG + cv * 8), g1 = *(const f32x4*)(sG + cv * 8 + 4);
                 const f32x4 b0 = *(const f32x4*)(sB + cv * 8), b1 = *(const f32x4*)(sB + cv * 8 + 4);
                 f16x8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    o[e] = (f16)fmaf((v[it][e] - mean) * rstd, e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]);
+                    o[e] = (f16)fmaf((val(it, e) - mean) * rstd, e < 4 ? g0[e] : g1[e - 4], e < 4 ? b0[e] : b1[e - 4]);
                 *(f16x8*)(yp + cv * 8) = o;
             }
         }
     }
 }
 
+template <int MAXIT, int LPR>
+static void launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, int ldx, int ldy, float eps,
+                             const float* rowvec, int rv_div, int rv_mod, int slots, hipStream_t st) {
+    // one round of resident workgroups: slots = CUs x workgroups per CU of this instantiation (occupancy API, cached)
+    static int wg_per_cu[2] = {0, 0};
+    int& wpc = wg_per_cu[rowvec ? 1 : 0];
+    if (wpc == 0) {
+        int nb = 0;
+        const void* fn = rowvec ? (const void*)layernorm_kernel<MAXIT, LPR, true> : (const void*)layernorm_kernel<MAXIT, LPR, false>;
+        wpc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) ? nb : 4;
+    }
+    slots = slots * wpc;
+    const int passes = cdiv(M, 256 / LPR);
+    const int nrr = cdiv(passes, slots);
+    const int grid = cdiv(passes, nrr);
+    if (rowvec)
+        hipLaunchKernelGGL((layernorm_kernel<MAXIT, LPR, true>), dim3(grid), dim3(256), 0, st, (const f16*)x, gamma, beta, (f16*)y, M, C,
+                           ldx, ldy, eps, rowvec, rv_div, rv_mod, nrr);
+    else
+        hipLaunchKernelGGL((layernorm_kernel<MAXIT, LPR, false>), dim3(grid), dim3(256), 0, st, (const f16*)x, gamma, beta, (f16*)y, M, C,
+                           ldx, ldy, eps, rowvec, rv_div, rv_mod, nrr);
+}
+
 extern "C" int mofa_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int M, int C, int ldx,
-                                  int ldy, float eps, const float* rowvec, int rv_div, int rv_mod,
-                                  mofa_stream_t stream) {
+                                  int ldy, float eps, const float* rowvec, int rv_div, int rv_mod, mofa_stream_t stream) {
     if (!x || !gamma || !beta || !y || M <= 0 || C <= 0 || C % 8 != 0 || C > 16 * 8 * LN_MAXIT || ldx % 8 != 0 || ldy % 8 != 0)
         return MOFA_EINVAL;
     if (rowvec && (rv_div <= 0 || rv_mod <= 0)) return MOFA_EINVAL;
     const int CV = C / 8;
-    const int grid = cdiv(M, 16 * LN_ROWS);
-    if (CV <= 48)
-        hipLaunchKernelGGL(layernorm_kernel<3>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma,
-                           beta, (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
-    else if (CV <= 80)
-        hipLaunchKernelGGL(layernorm_kernel<5>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)x, gamma,
-                           beta, (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
-    else
-        hipLaunchKernelGGL(layernorm_kernel<LN_MAXIT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const f16*)x,
-                           gamma, beta, (f16*)y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, cus = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+                cus > 0) ? cus : 256;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (CV <= 40 && CV % 8 == 0) launch_layernorm<5, 8>(x, gamma, beta, y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod, n_cu, st);
+    else if (CV <= 48) launch_layernorm<3, 16>(x, gamma, beta, y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod, n_cu, st);
+    else if (CV <= 80) launch_layernorm<5, 16>(x, gamma, beta, y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod, n_cu, st);
+    else launch_layernorm<LN_MAXIT, 16>(x, gamma, beta, y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod, n_cu, st);
     MOFA_CHECK_LAUNCH();
     return MOFA_OK;
 }
