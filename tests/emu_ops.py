@@ -67,6 +67,11 @@ def igemm(x, w, bias=None, geom=None, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30)
         y = F.relu(y)
     elif act == L.ACT_GELU:
         y = F.gelu(y)
+    elif act == L.ACT_GEGLU_PAIR:
+        # value / gate rows interleaved in blocks of 16 (weights.interleave_geglu): out[:, 16 b + c] = val * gelu(gate)
+        yb = y.reshape(M, N // 32, 2, 16)
+        y = (yb[:, :, 0] * F.gelu(yb[:, :, 1])).reshape(M, N // 2)
+        N = N // 2
     elif act != L.ACT_NONE:
         raise NotImplementedError
     if out is None:
@@ -77,16 +82,27 @@ def igemm(x, w, bias=None, geom=None, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30)
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=None):
-    assert rowvec is None
-    return F.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps).to(F16)
+    xf = x.float()
+    if rowvec is not None:
+        m = torch.arange(x.shape[0])
+        xf = xf + rowvec.float()[(m // rv_div) % rv_mod]
+    y = F.layer_norm(xf, (x.shape[1],), gamma, beta, eps).to(F16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None):
-    assert frames_per_stat == 1
     C = gamma.numel()
-    y = F.group_norm(x[:, :C].float().reshape(nframes, HW, C).permute(0, 2, 1), 32, gamma, beta, eps)
+    fps = frames_per_stat
+    y = F.group_norm(x[:, :C].float().reshape(nframes // fps, fps * HW, C).permute(0, 2, 1), 32, gamma, beta, eps)
     y = F.silu(y) if silu else y
-    return y.permute(0, 2, 1).reshape(nframes * HW, C).to(F16)
+    y = y.permute(0, 2, 1).reshape(nframes * HW, C).to(F16)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def gn_nparts(HW, Cc):
@@ -129,6 +145,49 @@ def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, 
         return t.float().reshape(nframes, S, heads, head_dim).permute(0, 2, 1, 3)
     p = torch.softmax(split(q) @ split(k).transpose(-1, -2) * scale, dim=-1)
     return (p @ split(v)).permute(0, 2, 1, 3).reshape(nframes * S, heads * head_dim).to(F16)
+
+
+def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=None, Tq=None, key_mask=None):
+    """k / v rows (clip, frame t < T, pixel); q / out rows (clip, frame i < Tq, pixel); key_mask bit j = key frame j exists"""
+    Tq = T if Tq is None else Tq
+    scale = head_dim ** -0.5 if scale is None else scale
+    C = heads * head_dim
+
+    def split(t, n):                       # -> [clip, pixel, head, frame, d]
+        return t[:, :C].float().reshape(nclips, n, HW, heads, head_dim).permute(0, 2, 3, 1, 4)
+    s = split(q, Tq) @ split(k, T).transpose(-1, -2) * scale
+    if key_mask is not None:
+        dead = torch.tensor([not ((key_mask >> j) & 1) for j in range(T)])
+        s = s.masked_fill(dead, float("-inf"))
+    o = torch.softmax(s, dim=-1) @ split(v, T)
+    return o.permute(0, 3, 1, 2, 4).reshape(nclips * Tq * HW, C).to(F16)
+
+
+def timestep_embedding(t, dim):
+    """csrc/elementwise.hip timestep_embedding_kernel: [cos | sin], frequencies exp(-ln(1e4) k / half)"""
+    half = dim // 2
+    freq = torch.exp(-9.210340371976184 * torch.arange(half, dtype=torch.float32) / half)
+    a = t.reshape(-1, 1).float() * freq
+    return torch.cat([torch.cos(a), torch.sin(a)], 1)
+
+
+def silu_f32(x):
+    return F.silu(x)
+
+
+def axpby_(x, y, a=1.0, b=1.0):
+    y.copy_((a * x.float() + b * y.float()).to(F16))
+    return y
+
+
+def axpby_out(x, y, a, b, out):
+    out.copy_((a * x.float() + b * y.float()).to(F16))
+    return out
+
+
+def copy2d(src, dst):
+    dst.copy_(src)
+    return dst
 
 
 def transpose_v(v, nframes, ncb, S):
@@ -193,7 +252,7 @@ def resize_nearest_f32(x, h, w):
     return torch.nn.functional.interpolate(x[None].float(), size=(h, w), mode="nearest")[0]
 
 
-NAMES = ["gn_nparts", "gn_partial_into", "gn_apply_gathered", "resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
+NAMES = ["attn_temporal", "timestep_embedding", "silu_f32", "axpby_", "axpby_out", "copy2d", "gn_nparts", "gn_partial_into", "gn_apply_gathered", "resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
          "tokens_to_nchw", "patchify", "filter1d_reflect", "resize_bicubic_ac"]
 
 
