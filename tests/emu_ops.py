@@ -155,11 +155,16 @@ def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=No
 
     def split(t, n):                       # -> [clip, pixel, head, frame, d]
         return t[:, :C].float().reshape(nclips, n, HW, heads, head_dim).permute(0, 2, 3, 1, 4)
-    s = split(q, Tq) @ split(k, T).transpose(-1, -2) * scale
-    if key_mask is not None:
+    kk, vv = split(k, T), split(v, T)
+    dead = None
+    if key_mask is not None:               # (the kernel never reads a masked frame's rows: they may hold anything)
         dead = torch.tensor([not ((key_mask >> j) & 1) for j in range(T)])
+        kk = kk.masked_fill(dead.view(1, 1, 1, T, 1), 0.0)
+        vv = vv.masked_fill(dead.view(1, 1, 1, T, 1), 0.0)
+    s = split(q, Tq) @ kk.transpose(-1, -2) * scale
+    if dead is not None:
         s = s.masked_fill(dead, float("-inf"))
-    o = torch.softmax(s, dim=-1) @ split(v, T)
+    o = torch.softmax(s, dim=-1) @ vv
     return o.permute(0, 3, 1, 2, 4).reshape(nclips * Tq * HW, C).to(F16)
 
 
