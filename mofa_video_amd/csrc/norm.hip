@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 // least 16 rows each.  (Until r04b: about 64 K elements per workgroup, which at level 0 made 2 250 workgroups for 2 048 slots: a
 // second round one tenth full, 4.5 TB/s where the same kernel streams 5.2 TB/s on 4 500 or 1 150 workgroups.)
 static int gn_apply_rows_per_wg(int HW, int C, int nframes, int total_entries) {
-    static int slots = 0;
+    static int slots = 0, n_cu_ = 256;
     if (slots == 0) {
         int dev = 0, cus = 0, nb = 0;
         if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
@@ -419,14 +419,18 @@ static int gn_apply_rows_per_wg(int HW, int C, int nframes, int total_entries) {
             cus = 256;
         // (4 KB of dynamic LDS: the occupancy of this kernel is bound by its 8 waves per SIMD, not by C * 8 bytes of LDS, up to C = 1280)
         if (!(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gn_apply_kernel, 256, 4096) == hipSuccess && nb > 0)) nb = 8;
+        n_cu_ = cus;
         slots = cus * nb;
     }
-    int chunks = slots / nframes;
+    // wide inputs (decoder concat buffers, C = 1920 / 2560) are bound by LDS instead: C * 8 B of scale / shift + 8.5 KB static of 160 KB
+    const int by_lds = 163840 / (C * 8 + 8704);
+    const int per_cu = slots / n_cu_;
+    int chunks = (by_lds < per_cu ? n_cu_ * (by_lds < 1 ? 1 : by_lds) : slots) / nframes;
     chunks = chunks < 1 ? 1 : chunks;
     int rpw = cdiv(HW, chunks);
     // (a floor of total_entries * 256 / C rows, so that a workgroup's re-read of its set's partial entries stays below a quarter of its
     // own bytes, was measured too: level-1 temporal norms 56 -> 70 us with 750 workgroups; the entries come from L2, the rows do not)
-    (void)C; (void)total_entries;
+    (void)total_entries;
     return rpw < 16 ? 16 : rpw;
 }
 
