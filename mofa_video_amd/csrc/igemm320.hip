@@ -48,8 +48,21 @@ template <int NJ> struct Geo {
     static constexpr int PLANE = (TBM3 + TBN) * RBH;           // 36 KB / 32 KB
     static constexpr int SLOT = 2 * PLANE;                     // one K tile
     static constexpr int BIAS0 = 2 * SLOT;                     // per wave 2 x 768 B: the bias of this tile and of the next one
+#ifdef MOFA_X_PREFETCH
+    // EXPERIMENT (prepared at the end of r04 without GPU time left; A/B it with tools/igemm_tiles_bench.py --lib): every wave adds
+    // ONE 4-byte-per-lane LDS-DMA per K tile (in the phase where it issues 4 pieces, so every phase carries 5) that touches the 128-byte
+    // line of 64 activation rows MOFA_X_PREFETCH K tiles AHEAD -- a prefetch into L2 (the 4 bytes land in a dummy 256-byte LDS slot per
+    // wave).  Why: the ring gives the real DMA about one K tile (~0.7 us) of flight, an HBM miss takes longer, and the launches whose
+    // activations stream from HBM (level-0 plain GEMMs: ff out 794, attention out 430, qkv 660 TF/s) sit far below the L2-fed ones
+    // (conv3x3 1 040-1 290); with X aliased to one row (all L2 hits) the r01 kernel gained 33-47 % on exactly these shapes
+    // (profiles/r01e_igemm_l2hit_experiment.log).
+    static constexpr int PF0 = BIAS0 + 8 * 2 * 768;            // 8 x 256 B of dummy prefetch targets
+    static constexpr int LDS_BYTES = PF0 + 8 * 256;            // 161792
+    static constexpr int LOOKAHEAD = 10;                       // every issue() is exactly 5 DMA instructions
+#else
     static constexpr int LDS_BYTES = BIAS0 + 8 * 2 * 768;     // 159744 (the epilogue transposes through a free ring plane)
     static constexpr int LOOKAHEAD = 4 + NJ;                   // DMA instructions of the last two phases may be in flight
+#endif
 };
 
 struct Cursor3 {                    // one K-half plane of the persistent K-tile stream
@@ -194,6 +207,11 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
 #else
     constexpr bool chunk_major = false;
 #endif
+#ifdef MOFA_X_PREFETCH
+    // byte offset of this lane's prefetch row inside a row tile (the ONE extra VGPR of the experiment); rows beyond M fall outside the
+    // descriptor: no fetch
+    const unsigned pf_lane = (unsigned)(64 * (wave & 3) + lane) * (unsigned)aux.ldxb;
+#endif
     auto issue = [&](Cursor3& c, const int p, const int slot) __attribute__((always_inline)) {
         if (chunk_major || c.ikc == 0) {
             const int l = lane_now();
@@ -207,6 +225,23 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         bglds16(rsw, c.wo0, wk, pl + XPL + wave * 1024);
         bglds16(rsw, c.wo0 + wd1, wk, pl + XPL + (wave + 8) * 1024);
         if (NJ3 == 5 && grp == p) bglds16(rsw, c.wo0 + wd2, wk, pl + XPL + (16 + (wave & 3)) * 1024);
+#ifdef MOFA_X_PREFETCH
+        if (NJ3 == 5 && grp != p) {
+            // rows 64 (wave & 3) + lane of the row tile this cursor is in, K tile ikc + PF (past the end of the K range: the first K
+            // tiles of the workgroup's NEXT tile); waves 0-3 do it on even K tiles, waves 4-7 on odd ones (one line per row and K tile);
+            // the other parity and the convolution modes issue the same instruction out of the descriptor's range (no fetch), so
+            // that every issue() counts 5 DMA instructions for the counted waits.
+            int kt = c.ikc + MOFA_X_PREFETCH, ph = c.phase, lc = c.local;
+            if (kt >= kpt) { kt -= kpt; next_pos(ph, lc); }
+            int tile_, kb_, ke_;
+            item_decode(ph, lc, tile_, kb_, ke_);
+            const int tm_ = fdiv(tile_, aux.tiles_n);
+            const bool on = a.mode == MOFA_MODE_PLAIN && ph == 0 && ((c.ksw ^ grp) & 1) == 0 && kt < kpt;
+            const unsigned voff = on ? pf_lane : XO_INVALID;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(smem + Geo<NJ3>::PF0 + wave * 256), 4, voff,
+                                                     on ? tm_ * TBM3 * aux.ldxb + kt * 128 : 0, 0, 0);
+        }
+#endif
     };
     auto advance = [&](Cursor3& c, const int p) __attribute__((always_inline)) {
         ++c.ksw;
