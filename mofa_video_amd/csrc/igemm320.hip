@@ -211,6 +211,9 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
     // byte offset of this lane's prefetch row inside a row tile (the ONE extra VGPR of the experiment); rows beyond M fall outside the
     // descriptor: no fetch
     const unsigned pf_lane = (unsigned)(64 * (wave & 3) + lane) * (unsigned)aux.ldxb;
+#ifdef MOFA_R_PREFETCH
+    const auto rsr = __builtin_amdgcn_make_buffer_rsrc((void*)a.r1, 0, a.r1 ? (unsigned)(((size_t)(a.M - 1) * a.ldr1 + a.N) * 2) : 0u, 0x00020000);
+#endif
 #endif
     auto issue = [&](Cursor3& c, const int p, const int slot) __attribute__((always_inline)) {
         if (chunk_major || c.ikc == 0) {
@@ -236,10 +239,29 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
             int tile_, kb_, ke_;
             item_decode(ph, lc, tile_, kb_, ke_);
             const int tm_ = fdiv(tile_, aux.tiles_n);
-            const bool on = a.mode == MOFA_MODE_PLAIN && ph == 0 && ((c.ksw ^ grp) & 1) == 0 && kt < kpt;
-            const unsigned voff = on ? pf_lane : XO_INVALID;
+            const bool xpar = ((c.ksw ^ grp) & 1) == 0;
+            const bool on = a.mode == MOFA_MODE_PLAIN && ph == 0 && xpar && kt < kpt;
+            unsigned voff = on ? pf_lane : XO_INVALID;
+            int soff = on ? tm_ * TBM3 * aux.ldxb + kt * 128 : 0;
+#ifdef MOFA_R_PREFETCH
+            // the other parity's slot: lines of the residual tile the CURRENT tile's epilogue will read (256 rows x 640 B = 1 280 lines of
+            // 128 B; K tile ksw of the tile covers lines [256 ksw, 256 ksw + 256): complete after 5 K tiles) -- the residual loads of a
+            // shallow-K epilogue are latency bound (a ring of 5 x 16 B per lane in flight)
+            if (R1 && !xpar && c.phase == 0 && c.ksw < 5) {
+                int tile_c, kb_c, ke_c;
+                item_decode(c.phase, c.local, tile_c, kb_c, ke_c);
+                const int tm_c = fdiv(tile_c, aux.tiles_n), tn_c = tile_c - tm_c * tilesN;
+                const int j = (c.ksw * 4 + (wave & 3)) * 64 + lane_now();
+                const int row = (int)(((unsigned)j * 52429u) >> 18);           // j / 5 for j < 1 280
+                const int m_ = tm_c * TBM3 + row;
+                voff = m_ < a.M ? (unsigned)row * (unsigned)(a.ldr1 * 2) + (unsigned)(j - 5 * row) * 128u : XO_INVALID;
+                soff = (tm_c * TBM3 * a.ldr1 + tn_c * TBN3) * 2;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, (__attribute__((address_space(3))) void*)(smem + Geo<NJ3>::PF0 + wave * 256), 4,
+                                                         voff, soff, 0, 0);
+            } else
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(smem + Geo<NJ3>::PF0 + wave * 256), 4, voff,
-                                                     on ? tm_ * TBM3 * aux.ldxb + kt * 128 : 0, 0, 0);
+                                                     soff, 0, 0);
         }
 #endif
     };
