@@ -48,21 +48,8 @@ template <int NJ> struct Geo {
     static constexpr int PLANE = (TBM3 + TBN) * RBH;           // 36 KB / 32 KB
     static constexpr int SLOT = 2 * PLANE;                     // one K tile
     static constexpr int BIAS0 = 2 * SLOT;                     // per wave 2 x 768 B: the bias of this tile and of the next one
-#ifdef MOFA_X_PREFETCH
-    // EXPERIMENT (prepared at the end of r04 without GPU time left; A/B it with tools/igemm_tiles_bench.py --lib): every wave adds
-    // ONE 4-byte-per-lane LDS-DMA per K tile (in the phase where it issues 4 pieces, so every phase carries 5) that touches the 128-byte
-    // line of 64 activation rows MOFA_X_PREFETCH K tiles AHEAD -- a prefetch into L2 (the 4 bytes land in a dummy 256-byte LDS slot per
-    // wave).  Why: the ring gives the real DMA about one K tile (~0.7 us) of flight, an HBM miss takes longer, and the launches whose
-    // activations stream from HBM (level-0 plain GEMMs: ff out 794, attention out 430, qkv 660 TF/s) sit far below the L2-fed ones
-    // (conv3x3 1 040-1 290); with X aliased to one row (all L2 hits) the r01 kernel gained 33-47 % on exactly these shapes
-    // (profiles/r01e_igemm_l2hit_experiment.log).
-    static constexpr int PF0 = BIAS0 + 8 * 2 * 768;            // 8 x 256 B of dummy prefetch targets
-    static constexpr int LDS_BYTES = PF0 + 8 * 256;            // 161792
-    static constexpr int LOOKAHEAD = 10;                       // every issue() is exactly 5 DMA instructions
-#else
     static constexpr int LDS_BYTES = BIAS0 + 8 * 2 * 768;     // 159744 (the epilogue transposes through a free ring plane)
     static constexpr int LOOKAHEAD = 4 + NJ;                   // DMA instructions of the last two phases may be in flight
-#endif
 };
 
 struct Cursor3 {                    // one K-half plane of the persistent K-tile stream
@@ -189,87 +176,29 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         if constexpr (SPLIT) {                                     // a slice may start in the middle of a tap
             int tap = fdiv(kb, aux.kpt_d);
             c.ikc = kb - tap * kpt;
-#ifdef MOFA_CONV_CHUNK_MAJOR
-            if (a.mode == MOFA_MODE_CONV3X3) { c.ikc = kb / taps; tap = kb - c.ikc * taps; }   // (chunk major: see `issue`)
-#endif
             c.ksw = kb;
             if (a.mode == MOFA_MODE_CONV3X3) { c.ky = fdiv(tap, aux.ks_d); c.kx = tap - c.ky * ks_; } else c.ky = tap;
             c.xo0 = tap_src(c.gx0, c.ky, c.kx, swz_bytes(l, p));
             c.xo1 = tap_src(c.gx1, c.ky, c.kx, swz_bytes(l, p));
         }
     };
-#ifdef MOFA_CONV_CHUNK_MAJOR
-    // EXPERIMENT (r04, verdict item 3d): k x k convolutions walk K CHANNEL CHUNK MAJOR -- for each 64-channel chunk all the taps -- so
-    // that the rows an XCD's 32 tiles share between taps (5 MB over the nine tap passes of the tap-major order at level 0: a 9 x
-    // re-fetch through the fabric) are re-read while they are still in the 4 MB L2 (1 MB per chunk).  Same products, another fp32
-    // summation order.  Cursor: ikc = chunk, (ky, kx) = tap, ksw = position in the stream (ksw = chunk * taps + tap).
-    const bool chunk_major = a.mode == MOFA_MODE_CONV3X3;
-#else
-    constexpr bool chunk_major = false;
-#endif
-#ifdef MOFA_X_PREFETCH
-    // byte offset of this lane's prefetch row inside a row tile (the ONE extra VGPR of the experiment); rows beyond M fall outside the
-    // descriptor: no fetch
-    const unsigned pf_lane = (unsigned)(64 * (wave & 3) + lane) * (unsigned)aux.ldxb;
-#ifdef MOFA_R_PREFETCH
-    const auto rsr = __builtin_amdgcn_make_buffer_rsrc((void*)a.r1, 0, a.r1 ? (unsigned)(((size_t)(a.M - 1) * a.ldr1 + a.N) * 2) : 0u, 0x00020000);
-#endif
-#endif
     auto issue = [&](Cursor3& c, const int p, const int slot) __attribute__((always_inline)) {
-        if (chunk_major || c.ikc == 0) {
+        if (c.ikc == 0) {
             const int l = lane_now();
             c.xo0 = tap_src(c.gx0, c.ky, c.kx, swz_bytes(l, p));
             c.xo1 = tap_src(c.gx1, c.ky, c.kx, swz_bytes(l, p));
         }
         char* pl = smem + slot + p * PLANE;
-        const int wk = chunk_major ? ((c.ky * ks_ + c.kx) * kpt + c.ikc) * 128 : c.ksw * 128;
+        const int wk = c.ksw * 128;
         bglds16(rsx, c.xo0, c.ikc * 128, pl + wave * 1024);
         bglds16(rsx, c.xo1, c.ikc * 128, pl + (wave + 8) * 1024);
         bglds16(rsw, c.wo0, wk, pl + XPL + wave * 1024);
         bglds16(rsw, c.wo0 + wd1, wk, pl + XPL + (wave + 8) * 1024);
         if (NJ3 == 5 && grp == p) bglds16(rsw, c.wo0 + wd2, wk, pl + XPL + (16 + (wave & 3)) * 1024);
-#ifdef MOFA_X_PREFETCH
-        if (NJ3 == 5 && grp != p) {
-            // rows 64 (wave & 3) + lane of the row tile this cursor is in, K tile ikc + PF (past the end of the K range: the first K
-            // tiles of the workgroup's NEXT tile); waves 0-3 do it on even K tiles, waves 4-7 on odd ones (one line per row and K tile);
-            // the other parity and the convolution modes issue the same instruction out of the descriptor's range (no fetch), so
-            // that every issue() counts 5 DMA instructions for the counted waits.
-            int kt = c.ikc + MOFA_X_PREFETCH, ph = c.phase, lc = c.local;
-            if (kt >= kpt) { kt -= kpt; next_pos(ph, lc); }
-            int tile_, kb_, ke_;
-            item_decode(ph, lc, tile_, kb_, ke_);
-            const int tm_ = fdiv(tile_, aux.tiles_n);
-            const bool xpar = ((c.ksw ^ grp) & 1) == 0;
-            const bool on = a.mode == MOFA_MODE_PLAIN && ph == 0 && xpar && kt < kpt;
-            unsigned voff = on ? pf_lane : XO_INVALID;
-            int soff = on ? tm_ * TBM3 * aux.ldxb + kt * 128 : 0;
-#ifdef MOFA_R_PREFETCH
-            // the other parity's slot: lines of the residual tile the CURRENT tile's epilogue will read (256 rows x 640 B = 1 280 lines of
-            // 128 B; K tile ksw of the tile covers lines [256 ksw, 256 ksw + 256): complete after 5 K tiles) -- the residual loads of a
-            // shallow-K epilogue are latency bound (a ring of 5 x 16 B per lane in flight)
-            if (R1 && !xpar && c.phase == 0 && c.ksw < 5) {
-                int tile_c, kb_c, ke_c;
-                item_decode(c.phase, c.local, tile_c, kb_c, ke_c);
-                const int tm_c = fdiv(tile_c, aux.tiles_n), tn_c = tile_c - tm_c * tilesN;
-                const int j = (c.ksw * 4 + (wave & 3)) * 64 + lane_now();
-                const int row = (int)(((unsigned)j * 52429u) >> 18);           // j / 5 for j < 1 280
-                const int m_ = tm_c * TBM3 + row;
-                voff = m_ < a.M ? (unsigned)row * (unsigned)(a.ldr1 * 2) + (unsigned)(j - 5 * row) * 128u : XO_INVALID;
-                soff = (tm_c * TBM3 * a.ldr1 + tn_c * TBN3) * 2;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsr, (__attribute__((address_space(3))) void*)(smem + Geo<NJ3>::PF0 + wave * 256), 4,
-                                                         voff, soff, 0, 0);
-            } else
-#endif
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(smem + Geo<NJ3>::PF0 + wave * 256), 4, voff,
-                                                     soff, 0, 0);
-        }
-#endif
     };
     auto advance = [&](Cursor3& c, const int p) __attribute__((always_inline)) {
         ++c.ksw;
-        if (chunk_major) {
-            if (++c.kx == ks_) { c.kx = 0; if (++c.ky == ks_) { c.ky = 0; ++c.ikc; } }
-        } else if (++c.ikc == kpt) {
+        if (++c.ikc == kpt) {
             c.ikc = 0;
             if (a.mode == MOFA_MODE_CONV3X3) { if (++c.kx == ks_) { c.kx = 0; ++c.ky; } } else ++c.ky;
         }

@@ -65,8 +65,10 @@ def denoise_and_decode(unet, controlnet, vae, scheduler, *args, decode_chunk_siz
 @torch.no_grad()
 def denoise_hybrid(unet, face_controlnet, drag_controlnet, scheduler, latents, image_latents, image_embeddings,
                    controlnet_condition, controlnet_flow, landmarks, drag_flow, mask, num_inference_steps=25,
-                   min_guidance_scale=1.0, max_guidance_scale=3.0, ctrl_scale_traj=1.0, ctrl_scale_ldmk=1.0):
-    """landmarks [1,T,3,H,W]; mask [1,1,H,W] (1 = face adapter, 0 = drag adapter); other args as ``denoise``."""
+                   min_guidance_scale=1.0, max_guidance_scale=3.0, ctrl_scale_traj=1.0, ctrl_scale_ldmk=1.0,
+                   return_trace=False):
+    """landmarks [1,T,3,H,W]; mask [1,1,H,W] (1 = face adapter, 0 = drag adapter); other args as ``denoise``.
+    return_trace: also the latents after every step (test bookkeeping, not in the reference)."""
     import torch.nn.functional as F
     num_frames = latents.shape[1]
     scheduler.set_timesteps(num_inference_steps)
@@ -80,6 +82,7 @@ def denoise_hybrid(unet, face_controlnet, drag_controlnet, scheduler, latents, i
     guidance_scale = torch.linspace(min_guidance_scale, max_guidance_scale, num_frames).unsqueeze(0)
     guidance_scale = guidance_scale.to(latents.device, latents.dtype)[(...,) + (None,) * 3]
     added_time_ids = make_added_time_ids(latents.dtype, latents.device)
+    trace = []
     for t in timesteps:
         x = torch.cat([latents] * 2)
         x = scheduler.scale_model_input(x, t)
@@ -103,7 +106,9 @@ def denoise_hybrid(unet, face_controlnet, drag_controlnet, scheduler, latents, i
         u, c = noise_pred.chunk(2)
         noise_pred = u + guidance_scale * (c - u)
         latents = scheduler.step(noise_pred, t, latents)
-    return latents
+        if return_trace:
+            trace.append(latents.clone())
+    return (latents, trace) if return_trace else latents
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -121,10 +126,16 @@ def window_views(num_frames, window_size, stride):
 def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, image_embeddings, controlnet_condition,
                           controlnet_flow, landmarks, window_size=25, stride=12, num_inference_steps=25,
                           min_guidance_scale=1.0, max_guidance_scale=3.0, controlnet_cond_scale=1.0,
-                          drag_controlnet=None, drag_flow=None, mask=None, ctrl_scale_traj=1.0):
+                          drag_controlnet=None, drag_flow=None, mask=None, ctrl_scale_traj=1.0, return_trace=False,
+                          reuse_identical_views=False):
     """latents [1,N,4,h,w]; controlnet_flow [1,N-1,2,H,W]; landmarks [1,N,3,H,W]; ``controlnet`` = landmark adapter.
     drag_controlnet / drag_flow / mask: BASELINE config 5's "hybrid control" inside the windows -- no reference file runs
-    it; it composes the window loop above with the Hybrid step's residual blend (Hybrid/pipeline/pipeline.py:479-489)."""
+    it; it composes the window loop above with the Hybrid step's residual blend (Hybrid/pipeline/pipeline.py:479-489).
+    return_trace: also the merged latents after every step.  reuse_identical_views (test bookkeeping, result-identical):
+    the reference's last view often repeats the one before it (:426-429, e.g. N = window_size gives (1,N) twice); every
+    window of a step reads the PREVIOUS step's latents and the networks are deterministic functions of their inputs, so a
+    repeated view's noise prediction IS the earlier one's -- it is taken from there instead of being recomputed; the Euler
+    step, the ``_step_index`` rewind and the overlap average still run once per view exactly as in the reference."""
     import torch.nn.functional as F
     num_frames = latents.shape[1]
     scheduler.set_timesteps(num_inference_steps)
@@ -142,11 +153,20 @@ def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, i
     views = window_views(num_frames, window_size, stride)
     count = torch.zeros_like(latents)
     value = torch.zeros_like(latents)
+    trace = []
     for t in timesteps:
         count.zero_()
         value.zero_()
+        seen = {}
         for idx, (t0, t1) in enumerate(views):                                        # :449-509
             lt = torch.cat([latents[:, 0:1], latents[:, t0:t1]], dim=1)
+            if reuse_identical_views and (t0, t1) in seen:
+                lt = scheduler.step(seen[(t0, t1)], t, lt)
+                if idx != len(views) - 1:
+                    scheduler._step_index -= 1
+                value[:, t0:t1] += lt[:, 1:]
+                count[:, t0:t1] += 1
+                continue
             il = torch.cat([image_latents[:, 0:1], image_latents[:, t0:t1]], dim=1)
             fl = controlnet_flow[:, (t0 - 1):(t1 - 1)]
             lm = torch.cat([landmarks[:, 0:1], landmarks[:, t0:t1]], dim=1)
@@ -172,6 +192,7 @@ def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, i
                               mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
             u, c = noise_pred.chunk(2)
             noise_pred = u + guidance_scale * (c - u)
+            seen[(t0, t1)] = noise_pred
             lt = scheduler.step(noise_pred, t, lt)
             if idx != len(views) - 1:
                 scheduler._step_index -= 1                                            # :499-500
@@ -182,4 +203,6 @@ def denoise_keypoint_loop(unet, controlnet, scheduler, latents, image_latents, i
                 value[:, t0:t1] += lt[:, 1:]
                 count[:, t0:t1] += 1
         latents = torch.where(count > 0, value / count, value)                        # :511
-    return latents
+        if return_trace:
+            trace.append(latents.clone())
+    return (latents, trace) if return_trace else latents

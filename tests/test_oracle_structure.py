@@ -115,3 +115,29 @@ def test_time_context_quirk_is_pixel_parity():
     # with B = 2: batch 0 differs at odd pixels, batch 1 at even pixels
     assert (flat[0, :, 0::2] < 1e-6).all() and (flat[0, :, 1::2] > 1e-6).all()
     assert (flat[1, :, 1::2] < 1e-6).all() and (flat[1, :, 0::2] > 1e-6).all()
+
+
+def test_keypoint_loop_view_reuse_is_result_identical():
+    """``denoise_keypoint_loop(reuse_identical_views=True)`` (what the full-geometry GPU parity tests run, to halve the
+    checker's time) against the literal loop that recomputes every view (svdxt_pipeline_ctrlnet_loop.py:426-511)"""
+    import torch
+    from helpers import LDMK_CN, LDMK_UNET, synthetic_inputs, synthetic_landmarks
+    from mofa_video_amd import schema
+    from oracle.ldmk import LandmarkFlowControlNet as OLdmk
+    from oracle.pipeline import denoise_keypoint_loop, window_views
+    from oracle.scheduler import EulerDiscreteScheduler as OSch
+    from oracle.unet import UNetSpatioTemporalConditionControlNetModel as OUnet
+    N, Tw, Hs, Ws = 5, 4, 128, 128
+    views = window_views(N, Tw, 1)
+    assert len(views) != len(set(views))                                            # the last view repeats
+    inp = synthetic_inputs(N, Hs, Ws, cross_dim=LDMK_UNET["cross_attention_dim"])
+    lm = synthetic_landmarks(N, Hs, Ws)
+    ou, ol = OUnet(**LDMK_UNET), OLdmk(**LDMK_CN)
+    ou.load_state_dict({k: v.float() for k, v in schema.synthetic_state_dict(schema.unet_schema(LDMK_UNET), seed=0).items()})
+    ol.load_state_dict({k: v.float() for k, v in schema.synthetic_state_dict(schema.ldmk_controlnet_schema(LDMK_CN), seed=7).items()})
+    args = (inp["latents"], inp["image_latents"], inp["image_embeddings"], inp["cond"], inp["flow"], lm)
+    kw = dict(window_size=Tw, stride=1, num_inference_steps=2)
+    with torch.no_grad():
+        a, ta = denoise_keypoint_loop(ou.eval(), ol.eval(), OSch(), *args, return_trace=True, **kw)
+        b, tb = denoise_keypoint_loop(ou, ol, OSch(), *args, return_trace=True, reuse_identical_views=True, **kw)
+    assert torch.equal(a, b) and all(torch.equal(x, y) for x, y in zip(ta, tb))
