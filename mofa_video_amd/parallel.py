@@ -31,6 +31,7 @@ cover, the host never blocks on the transport.
 ``ThreadComm`` (virtual ranks as threads of one process -- lets the whole sharded HIP path be checked against the
 unsharded one on a single GPU).
 """
+import os
 import threading
 
 import torch
@@ -85,9 +86,14 @@ class TorchComm:
     """torch.distributed backend (process group must be initialised).  Sub-groups are created once, by every rank,
     in the same order (a torch.distributed requirement)."""
 
-    def __init__(self, layout_of_rank):
+    # RCCL has never carried the two-network lockstep order on real links (every SCALE record so far is a skipped one): the
+    # single-stream order is the default on this transport; MOFA_SHARD_TWO_STREAMS=1 (the same on every rank) opts in
+    two_streams_default = os.environ.get("MOFA_SHARD_TWO_STREAMS", "0") == "1"
+
+    def __init__(self, layout_of_rank, two_lanes=None):
         import torch.distributed as dist
         self.dist = dist
+        two_lanes = self.two_streams_default if two_lanes is None else two_lanes
         self.rank = dist.get_rank()
         world = dist.get_world_size()
         self._groups = {}
@@ -97,21 +103,28 @@ class TorchComm:
             for g in (tuple(lay.frame_group), tuple(lay.pair_group)):
                 if g not in seen:
                     seen.append(g)
-        # per group of ranks four communicators, so that a small latency-bound exchange never queues behind a bulk transfer and
-        # the two networks of a step (lanes 0 / 1) never queue behind each other's token gathers: "" = bulk of lane 0 (token
-        # gather, final latents, CFG pair), "bulk1" = token gather of lane 1, "ctl" = GroupNorm partials, "data" = halo frames.
-        # Created by every rank in the same order (a torch.distributed requirement).
-        self._ctl, self._data, self._bulk1 = {}, {}, {}
-        for g in seen:
-            many = len(g) > 1
-            self._groups[g] = dist.new_group(list(g)) if many else None
-            self._ctl[g] = dist.new_group(list(g)) if many else None
-            self._data[g] = dist.new_group(list(g)) if many else None
-            self._bulk1[g] = dist.new_group(list(g)) if many else None     # bulk transfers of the step's second network
+        # per group of ranks: "" = bulk (token gather, final latents, CFG pair), "ctl" = GroupNorm partials, "data" = halo
+        # frames -- a small latency-bound exchange never queues behind a bulk transfer.  With ``two_lanes`` (the two networks
+        # of a step enqueued in lockstep on two HIP streams, FrameParallel.two_streams) the step's second network gets its OWN
+        # three communicators, so that no exchange of one network queues behind the other network's stream (round-4 advice:
+        # lane 1's partials gather on a shared "ctl" communicator would wait for lane 0's compute stream).  Created by every
+        # rank in the same order (a torch.distributed requirement); ``two_lanes`` must therefore be the same on every rank.
+        self.two_lanes = two_lanes
+        self._lanes = []
+        for lane in range(2 if two_lanes else 1):
+            comms = {}
+            for kind in ("bulk", "ctl", "data"):
+                comms[kind] = {g: (dist.new_group(list(g)) if len(g) > 1 else None) for g in seen}
+            self._lanes.append(comms)
+        self._groups = self._lanes[0]["bulk"]
         self._world_group = None
 
     def _g(self, ranks):
         return self._groups[tuple(ranks)]
+
+    def _lane(self, lane):
+        """the communicator set of a network lane (lane 1 falls back to lane 0's when the second set was not created)"""
+        return self._lanes[lane if lane < len(self._lanes) else 0]
 
     def all_reduce_sum(self, t, ranks):
         if len(ranks) > 1:
@@ -141,22 +154,22 @@ class TorchComm:
         if len(ranks) == 1:
             return _Done()
         i = list(ranks).index(self.rank)
-        grp = self._bulk1[tuple(ranks)] if lane else self._g(ranks)
+        grp = self._lane(lane)["bulk"][tuple(ranks)]
         return self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=grp, async_op=True)
 
-    def gather_small_into(self, buf, slot_rows, ranks):
-        """the in-place all-gather of ``all_gather_into`` on the "ctl" communicator, complete in stream order when it returns
-        (the current stream waits for it; the host does not block on RCCL)"""
+    def gather_small_into(self, buf, slot_rows, ranks, lane=0):
+        """the in-place all-gather of ``all_gather_into`` on the lane's "ctl" communicator, complete in stream order when it
+        returns (the current stream waits for it; the host does not block on RCCL)"""
         if len(ranks) > 1:
             i = list(ranks).index(self.rank)
-            self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=self._ctl[tuple(ranks)])
+            self.dist.all_gather_into_tensor(buf, buf[i * slot_rows:(i + 1) * slot_rows], group=self._lane(lane)["ctl"][tuple(ranks)])
         return buf
 
-    def halo_begin(self, first, last, prev_rank, next_rank, ranks):
+    def halo_begin(self, first, last, prev_rank, next_rank, ranks, lane=0):
         """send `first` to prev and `last` to next; receive prev's last and next's first (None at the clip ends).
-        Asynchronous (the "data" communicator's stream): ``wait()`` -> (from_prev, from_next) makes the current stream wait."""
+        Asynchronous (the lane's "data" communicator's stream): ``wait()`` -> (from_prev, from_next) makes the current stream wait."""
         dist = self.dist
-        grp = self._data[tuple(ranks)]
+        grp = self._lane(lane)["data"][tuple(ranks)]
         ops, from_prev, from_next = [], None, None
         if prev_rank is not None:
             from_prev = torch.empty_like(last)
@@ -257,11 +270,11 @@ class ThreadComm:
                 buf[j * slot_rows:(j + 1) * slot_rows].copy_(g)
         return _Done()
 
-    def gather_small_into(self, buf, slot_rows, ranks):
+    def gather_small_into(self, buf, slot_rows, ranks, lane=0):
         self.all_gather_into(buf, slot_rows, ranks)
         return buf
 
-    def halo_begin(self, first, last, prev_rank, next_rank, ranks):
+    def halo_begin(self, first, last, prev_rank, next_rank, ranks, lane=0):
         if len(ranks) == 1:
             return _HaloWork([], None, None)
         got = self._exchange((first, last), ranks)
@@ -281,7 +294,9 @@ class FrameParallel:
         self.p2p = p2p
         self.kv_inplace = True      # temporal attention K|V: in-place asynchronous all_gather_into_tensor (else: compacting gather)
         self.gather_hidden = True   # ... of the normed hidden tokens (C columns; K|V projected after the gather) instead of K|V (2C)
-        self.two_streams = True     # adapter trunk || UNet encoder on two HIP streams, enqueued layer by layer in lockstep
+        # adapter trunk || UNet encoder on two HIP streams, enqueued layer by layer in lockstep: the transport's default (on for
+        # the in-process ThreadComm; OFF for TorchComm until an N-GPU RCCL run has been recorded, MOFA_SHARD_TWO_STREAMS=1)
+        self.two_streams = getattr(comm, "two_streams_default", True)
         self.split_convs = False    # (3,1,1) convolutions as interior + boundary launches while the halo frames travel: OFF --
                                     # on the 1-GPU proxy of a rank of 8 the extra launches cost 3.1 ms of a 49 ms step while
                                     # all halo frames of a step are <= 2.5 ms of wire time that the second network already
@@ -302,6 +317,7 @@ class FrameParallel:
         timeout (torch.distributed's default), not in this check.  Returns a dict for the caller to report.  Meant for the
         first run on a new transport: bench.py calls it in shard mode."""
         lay, grp = self.lay, self.lay.frame_group
+        device = torch.device(device)
         report = {"kv_gather": "in-place all_gather_into_tensor", "halo": "batched p2p" if self.p2p else "all_gather"}
         if len(grp) == 1:
             return report
@@ -352,6 +368,65 @@ class FrameParallel:
             if float(flag.item()) < len(grp):
                 self.p2p = False
                 report["halo"] = "all_gather (the batched p2p path failed its self-check)"
+        # --- two networks in lockstep on two streams: one exchange group (partials, halo, tokens) of lane 0 on a side stream
+        # interleaved with lane 1's on the caller's stream, in the order run_lockstep issues them; wrong data or an exception
+        # switches the overlap off on every rank of the group (a hang cannot be caught here: see above)
+        report["order"] = "two streams, lockstep" if self.two_streams else "one stream"
+        if self.two_streams:
+            ok = 1.0
+            try:
+                cuda = device.type == "cuda"
+                side = torch.cuda.Stream(device=device) if cuda else None
+                import contextlib
+                results = {}
+                for step in ("partials", "halo", "tokens"):
+                    for lane in (0, 1):
+                        ctx = torch.cuda.stream(side) if (cuda and lane == 0) else contextlib.nullcontext()
+                        self.lane = lane
+                        with ctx:
+                            if step == "partials":
+                                buf, own = self.part_buffer(2, device)
+                                own.copy_((pattern(lay.shard, lay.T_loc * 2)[:, :1] + 256.0 * lane).float().repeat(1, 64))
+                                results[(step, lane)] = self.gather_partials(buf, 2)
+                            elif step == "halo":
+                                x = pattern(lay.shard, lay.T_loc * rows) + 512.0 * lane
+                                results[(step, lane)] = self.halo_begin(x, rows)
+                            else:
+                                buf, own = self.kv_buffer(rows, C, device)
+                                buf.zero_()
+                                own.copy_(mine + 256.0 * lane)
+                                results[(step, lane)] = (buf, self.kv_gather_begin(buf, rows))
+                for lane in (0, 1):
+                    ctx = torch.cuda.stream(side) if (cuda and lane == 0) else contextlib.nullcontext()
+                    with ctx:
+                        pb = results[("partials", lane)]
+                        fp, fn = results[("halo", lane)].wait()
+                        kb, work = results[("tokens", lane)]
+                        work.wait()
+                        for s_, (a, b) in enumerate(lay.bounds):
+                            want = (pattern(s_, (b - a) * 2)[:, :1] + 256.0 * lane).float().repeat(1, 64)
+                            if not torch.equal(pb[s_ * lay.T_max * 2:s_ * lay.T_max * 2 + (b - a) * 2], want):
+                                ok = 0.0
+                            n = (b - a) * rows
+                            if not torch.equal(kb[s_ * lay.T_max * rows:s_ * lay.T_max * rows + n], ref[s_][:n] + 256.0 * lane):
+                                ok = 0.0
+                        if lay.prev_rank is not None:
+                            ta, tb = lay.bounds[lay.shard - 1]
+                            if not torch.equal(fp, (pattern(lay.shard - 1, (tb - ta) * rows) + 512.0 * lane)[-rows:]):
+                                ok = 0.0
+                        if lay.next_rank is not None and not torch.equal(fn, (pattern(lay.shard + 1, rows) + 512.0 * lane)):
+                            ok = 0.0
+                if cuda:
+                    torch.cuda.current_stream(device).wait_stream(side)
+            except Exception as e:  # noqa: BLE001
+                ok = 0.0
+                report["order_error"] = repr(e)[:200]
+            self.lane = 0
+            flag = torch.tensor([ok], dtype=torch.float64, device=device)
+            self.comm.all_reduce_sum(flag, grp)
+            if float(flag.item()) < len(grp):
+                self.two_streams = False
+                report["order"] = "one stream (the two-lane exchange failed its self-check)"
         return report
 
     # temporal GroupNorm statistics ----------------------------------------------------------------------------
@@ -373,7 +448,7 @@ class FrameParallel:
         """all ranks' partials into ``buf`` (in place; complete in stream order on return)"""
         if self.log is not None:
             self.log.append((self.lane, "partials"))
-        return self.comm.gather_small_into(buf, self.lay.T_max * nparts, self.lay.frame_group)
+        return self.comm.gather_small_into(buf, self.lay.T_max * nparts, self.lay.frame_group, lane=self.lane)
 
     # temporal conv halo -----------------------------------------------------------------------------------
     def halo_begin(self, x, HW):
@@ -384,7 +459,7 @@ class FrameParallel:
         if self.log is not None:
             self.log.append((self.lane, "halo"))
         if self.p2p:
-            return self.comm.halo_begin(first, last, lay.prev_rank, lay.next_rank, lay.frame_group)
+            return self.comm.halo_begin(first, last, lay.prev_rank, lay.next_rank, lay.frame_group, lane=self.lane)
         got = self.comm.all_gather(torch.cat([first, last], 0), lay.frame_group)      # conservative path (self_check)
         fp = got[lay.shard - 1][HW:] if lay.prev_rank is not None else None
         fn = got[lay.shard + 1][:HW] if lay.next_rank is not None else None

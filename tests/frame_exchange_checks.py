@@ -64,4 +64,23 @@ def check_frame_exchanges(rank, world, T, HW, C, device):
     assert not par.kv_inplace and "compacting" in rep["kv_gather"], (rank, rep)
     assert torch.equal(par.gather_frames(mine, HW), full)
     par.kv_inplace = True
+    # RCCL / gloo transports run the single-stream order unless opted in (round-4 advice); with two lanes every network has its
+    # own bulk / ctl / data communicators and the self-check exercises one interleaved exchange group on both of them
+    assert not par.two_streams and rep["order"] == "one stream", rep
+    par2 = FrameParallel(lay, TorchComm(lambda r: Layout(world, r, T, cfg_ranks=1), two_lanes=True))
+    par2.two_streams = True
+    rep2 = par2.self_check(device)
+    assert par2.two_streams and rep2["order"].startswith("two streams") and "order_error" not in rep2, (rank, rep2)
+    orig_h = par2.halo_begin
+    if rank == world - 1:                                                  # lane 1's halo frames arrive corrupted on ONE rank
+        def broken_h(x, HW_):
+            w = orig_h(x, HW_)
+            if par2.lane == 1 and w.res[0] is not None:
+                w.wait()
+                w.res[0][0, 0] += 1.0
+            return w
+        par2.halo_begin = broken_h
+    rep2 = par2.self_check(device)
+    par2.halo_begin = orig_h
+    assert not par2.two_streams and rep2["order"].startswith("one stream"), (rank, rep2)
     return par, full, mine
