@@ -655,7 +655,7 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
         }
         wait_lds();
     };
-    // ---- residuals and / or a per-row vector: 32 x 32 fp32 transposes (the sum is rounded once); a lane owns 8 consecutive
+    // ---- residuals and / or a per-row vector: 32 x 32 fp32 transposes; a lane owns 8 consecutive
     //      columns of one row.  The loads of step s + D are issued before step s is processed (ring of D steps in registers) ----
     auto epilogue_rows = [&](auto un, f32x16 (&acc)[MI3][NJ3], const int mw, const int nw, char* eb) __attribute__((always_inline)) {
         constexpr bool RVROW = RV && decltype(un)::v == 0;         // the row vector was NOT folded into the accumulators
@@ -722,6 +722,9 @@ __global__ __launch_bounds__(512, 2) void igemm320_f16_kernel(const mofa_igemm_a
                     float x0 = v0[e], x1 = v1[e];
                     if (RVROW) { x0 += l.rv0[p][e]; x1 += l.rv1[p][e]; }
                     x0 *= saccv; x1 *= saccv;
+                    // (with residuals the layer's own output is rounded to fp16 BEFORE the add, like epilogue_res16 and the
+                    //  reference's fp16 modules: every tile of a launch rounds the same way -- round-4 advice)
+                    if (R1 || R2) { x0 = (float)(f16)x0; x1 = (float)(f16)x1; }
                     if (R1) { x0 += s1v * (float)l.t1[p][e]; x1 += s1v * (float)l.t1[p][4 + e]; }
                     if (R2) { x0 += s2v * (float)l.t2[p][e]; x1 += s2v * (float)l.t2[p][4 + e]; }
                     o[e] = (f16)x0; o[4 + e] = (f16)x1;
@@ -901,6 +904,10 @@ __global__ __launch_bounds__(256) void igemm320_fixup_kernel(const mofa_igemm_ar
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] *= a.s_acc;
+        if (a.r1 || a.r2) {                                        // rounded to fp16 before the residual add, as in the whole tiles
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)(f16)v[e];
+        }
         if (a.r1) {
             const f16x8 t = *(const f16x8*)((const f16*)a.r1 + (size_t)m * a.ldr1 + n);
 #pragma unroll

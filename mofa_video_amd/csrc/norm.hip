@@ -411,17 +411,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
 // least 16 rows each.  (Until r04b: about 64 K elements per workgroup, which at level 0 made 2 250 workgroups for 2 048 slots: a
 // second round one tenth full, 4.5 TB/s where the same kernel streams 5.2 TB/s on 4 500 or 1 150 workgroups.)
 static int gn_apply_rows_per_wg(int HW, int C, int nframes, int total_entries) {
-    static int slots = 0, n_cu_ = 256;
-    if (slots == 0) {
+    // launch geometry of this chip, taken ONCE: a function-local static with an initialiser is initialised thread-safely (C++11), so the
+    // virtual-rank threads of the tests / several host threads cannot race on it (round-4 advice); every GPU of a node is the same part
+    struct Chip { int cus, slots; };
+    static const Chip chip = [] {
         int dev = 0, cus = 0, nb = 0;
         if (!(hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
               cus > 0))
             cus = 256;
         // (4 KB of dynamic LDS: the occupancy of this kernel is bound by its 8 waves per SIMD, not by C * 8 bytes of LDS, up to C = 1280)
         if (!(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gn_apply_kernel, 256, 4096) == hipSuccess && nb > 0)) nb = 8;
-        n_cu_ = cus;
-        slots = cus * nb;
-    }
+        return Chip{cus, cus * nb};
+    }();
+    const int slots = chip.slots, n_cu_ = chip.cus;
     // wide inputs (decoder concat buffers, C = 1920 / 2560) are bound by LDS instead: C * 8 B of scale / shift + 8.5 KB static of 160 KB
     const int by_lds = 163840 / (C * 8 + 8704);
     const int per_cu = slots / n_cu_;
@@ -581,13 +583,15 @@ template <int MAXIT, int LPR>
 static void launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int C, int ldx, int ldy, float eps,
                              const float* rowvec, int rv_div, int rv_mod, int slots, hipStream_t st) {
     // one round of resident workgroups: slots = CUs x workgroups per CU of this instantiation (occupancy API, cached)
-    static int wg_per_cu[2] = {0, 0};
-    int& wpc = wg_per_cu[rowvec ? 1 : 0];
-    if (wpc == 0) {
+    static const int wpc_rv = [] {
         int nb = 0;
-        const void* fn = rowvec ? (const void*)layernorm_kernel<MAXIT, LPR, true> : (const void*)layernorm_kernel<MAXIT, LPR, false>;
-        wpc = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) == hipSuccess && nb > 0) ? nb : 4;
-    }
+        return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)layernorm_kernel<MAXIT, LPR, true>, 256, 0) == hipSuccess && nb > 0) ? nb : 4;
+    }();
+    static const int wpc_plain = [] {
+        int nb = 0;
+        return (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)layernorm_kernel<MAXIT, LPR, false>, 256, 0) == hipSuccess && nb > 0) ? nb : 4;
+    }();
+    const int wpc = rowvec ? wpc_rv : wpc_plain;
     slots = slots * wpc;
     const int passes = cdiv(M, 256 / LPR);
     const int nrr = cdiv(passes, slots);
@@ -606,12 +610,11 @@ extern "C" int mofa_layernorm_f16(const void* x, const float* gamma, const float
         return MOFA_EINVAL;
     if (rowvec && (rv_div <= 0 || rv_mod <= 0)) return MOFA_EINVAL;
     const int CV = C / 8;
-    static int n_cu = 0;
-    if (n_cu == 0) {
+    static const int n_cu = [] {
         int dev = 0, cus = 0;
-        n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        return (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
                 cus > 0) ? cus : 256;
-    }
+    }();
     hipStream_t st = (hipStream_t)stream;
     if (CV <= 40 && CV % 8 == 0) launch_layernorm<5, 8>(x, gamma, beta, y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod, n_cu, st);
     else if (CV <= 48) launch_layernorm<3, 16>(x, gamma, beta, y, M, C, ldx, ldy, eps, rowvec, rv_div, rv_mod, n_cu, st);

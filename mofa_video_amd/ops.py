@@ -215,8 +215,14 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
         TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot,
                    tag=(mode, geom.stride, geom.up, M, N, Ktot, act))
     if st is not None:
-        out.gn_stats = st
+        out.gn_stats = (st, out._version, out.data_ptr())     # (group_norm ignores them if torch saw an in-place write since)
     return out
+
+
+def _written(t):
+    """an entry point of this module is about to write ``t`` in place: pair sums a producer attached describe the old values"""
+    if getattr(t, "gn_stats", None) is not None:
+        del t.gn_stats
 
 
 # ---- normalisation -------------------------------------------------------------------------------------
@@ -232,6 +238,10 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
     part = torch.empty((nframes, nparts, 32, 2), dtype=F32, device=x.device)
     st = L.stream_ptr()
     pairs = getattr(x, "gn_stats", None)                      # pair sums the producing igemm epilogue emitted (igemm(stats=True))
+    if pairs is not None:                                     # ... valid only for the very tensor object / values the producer left
+        pairs, ver, dptr = pairs
+        if ver != x._version or dptr != x.data_ptr():
+            pairs = None
     if pairs is not None and HW % 64 == 0 and Cc % 64 == 0 and tuple(pairs.shape) == (nframes * HW // 64, Cc) == (x.shape[0] // 64, x.shape[1]):
         L.check(lib.mofa_gn_partial_from_stats(L.ptr(pairs), L.ptr(part), nframes, HW, Cc, st), "mofa_gn_partial_from_stats")
         del x.gn_stats                                            # one shot: they describe x as the producer left it
@@ -352,6 +362,7 @@ def axpby_(x, y, a=1.0, b=1.0):
     """y = a*x + b*y (in place on y)."""
     lib = L.load()
     assert x.shape == y.shape
+    _written(y)
     L.check(lib.mofa_axpby_f16(L.ptr(x), L.ptr(y), x.shape[0], x.shape[1], _ld(x), _ld(y), a, b, L.stream_ptr()),
             "mofa_axpby_f16")
     return y
@@ -361,6 +372,7 @@ def axpby_out(x, y, a, b, out):
     """out = a*x + b*y (x, y untouched; out may be a column slice of a wider buffer)"""
     lib = L.load()
     assert x.shape == y.shape == out.shape
+    _written(out)
     L.check(lib.mofa_axpby_out_f16(L.ptr(x), L.ptr(y), L.ptr(out), x.shape[0], x.shape[1], _ld(x), _ld(y), _ld(out), a, b,
                                    L.stream_ptr()), "mofa_axpby_out_f16")
     return out

@@ -27,7 +27,7 @@ def softsplat(tenIn: torch.Tensor, tenFlow: torch.Tensor, tenMetric: torch.Tenso
     assert tenIn.is_cuda and tenFlow.is_cuda, "softsplat: CUDA/HIP tensors required (as in the reference)"
     N, C, H, W = tenIn.shape
     assert tenFlow.shape == (N, 2, H, W)
-    if strMode == 'sum':
+    if strMode.split('-')[0] == 'sum':       # 'sum' and 'sum-<suffix>': the raw splat, nothing is normalised (softsplat.py:252)
         return ops.softsplat_scatter_f32(tenIn.float().contiguous(), tenFlow.float().contiguous())
     if strMode == 'avg':
         Cp = (C + 7) // 8 * 8

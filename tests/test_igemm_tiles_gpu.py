@@ -292,6 +292,35 @@ def test_split_k_remainder_tiles_256x320(ops, M, N, K, kind):
     assert torch.equal(split, ops.igemm(x, w, bias, tile=TILES["256x320"], split_k=True, **kw))
 
 
+@pytest.mark.parametrize("kind", ["r1 s1=1", "r1 s1=0.5", "r1r2", "r1 + uniform row vector"])
+def test_split_and_whole_tiles_round_alike(ops, kind):
+    """round-4 advice: every tile of a launch must round the same way -- the whole 256x320 tiles round s_acc * acc to fp16 and then
+    add the residual (the reference's fp16 module semantics), so the split-K remainder tiles (fix-up kernel) must too.  With
+    operands whose products and sums are EXACT in fp32 (small integers x multiples of 2^-4) the summation order cannot matter,
+    so a split and a whole-tile launch have to agree bit for bit."""
+    M, N, K = 10317, 640, 2560                                  # 82 tiles: a partial round -> remainder tiles are split
+    g = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randint(-3, 4, (M, K), generator=g, device=DEV).half()
+    w = (torch.randint(-2, 3, (N, K), generator=g, device=DEV).float() / 16).half()
+    bias = torch.randint(-64, 65, (N,), generator=g, device=DEV).float() / 16
+    kw = dict(s_acc=0.75, r1=_h(M, N, seed=78), s1=1.0)
+    if kind == "r1 s1=0.5":
+        kw["s1"] = 0.5
+    elif kind == "r1r2":
+        kw.update(r2=_h(M, N, seed=79), s2=0.25)
+    elif kind.endswith("row vector"):
+        kw.update(rowvec=torch.randint(-64, 65, (3, N), generator=g, device=DEV).float() / 16, rv=(4096, 1, 1, 3))
+    whole = ops.igemm(x, w, bias, tile=TILES["256x320"], split_k=False, **kw)
+    split = ops.igemm(x, w, bias, tile=TILES["256x320"], split_k=True, **kw)
+    acc = x.float() @ w.float().t() + bias
+    if "rowvec" in kw:
+        acc = acc + kw["rowvec"][(torch.arange(M, device=DEV) // 4096) % 3]
+    ref = (0.75 * acc).half().float() + kw["s1"] * kw["r1"].float() + (kw["s2"] * kw["r2"].float() if "r2" in kw else 0.0)
+    d = (whole.float() - split.float()).abs().max().item()
+    assert torch.equal(whole, split), f"{kind}: split-K remainder tiles round differently from whole tiles (max diff {d:.3e})"
+    assert (whole.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("mode", ["conv3x3", "conv3x3_s2", "convt3", "convt3_halo"])
 def test_split_k_convolutions_slices_start_inside_a_tap(ops, mode):
     """split-K on the implicit-GEMM convolutions: the K slices of a remainder tile start in the MIDDLE of a tap (9 or 3 taps of

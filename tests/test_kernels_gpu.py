@@ -365,7 +365,7 @@ def test_softsplat_scatter_vs_oracle(ops):
     _close(out, softsplat_sum(x, flow), tol=1e-5, what="softsplat scatter")
 
 
-@pytest.mark.parametrize("mode", ["linear", "soft", "linear-zeroeps", "soft-clipeps", "soft-addeps", "avg-zeroeps", "avg", "sum"])
+@pytest.mark.parametrize("mode", ["linear", "soft", "linear-zeroeps", "soft-clipeps", "soft-addeps", "avg-zeroeps", "avg", "sum", "sum-addeps"])
 def test_softsplat_modes_vs_oracle(mode):
     """the reference wrapper's strMode surface (Traj/models/softsplat.py:232-274) through mofa_video_amd.softsplat, vs the oracle"""
     from mofa_video_amd.softsplat import softsplat as splat
