@@ -470,11 +470,11 @@ def main():
     # Roofline leg: HIP events around every implicit-GEMM / attention / softsplat launch of the LAST clip of the timed region
     # (on the launch stream), and that clip runs in SINGLE-STREAM order.  Two reasons, both measured:
     #  * bracketing all K clips costs 2.3 % of the clip time (two event records per launch x 19 000 timed launches per clip:
-    #    6 674 against 6 525 ms, profiles/r03c_bench_{timer,notimer}.log), which `value` would carry;
+    #    6 674 against 6 525 ms, profiles/archive/r03c_bench_{timer,notimer}.log), which `value` would carry;
     #  * the pipeline enqueues the adapter's ControlNet trunk and the UNet's encoder half on two HIP streams (pipeline.py,
     #    _denoise_forward: 3.0-4.4 % of a step).  A launch's event (or rocprofv3) duration then includes the time it waits for
     #    the CUs the other stream's kernel holds, so it no longer measures the kernel: the per-launch durations are taken with
-    #    nothing running beside (the same mode as profiles/r03*_kernel_stats_bench.md, `--single-stream`).
+    #    nothing running beside (the same mode as profiles/archive/r03*_kernel_stats_bench.md, `--single-stream`).
     # `value` is still all K clips / the whole timed region, the instrumented one included; config.clip_ms has both kinds.
     timer = ops.LaunchTimer()
     pipe.overlap_adapter = not args.single_stream
@@ -557,8 +557,10 @@ def main():
                               "the stepped window latents per round; VAE chunks dealt over all ranks" if cfg == 5 else
                               f"one clip over {world} GPUs: 2-way CFG x {max(world // 2, 1)}-way frame shards; RCCL: per temporal "
                               "norm + conv one exchange group (raw halo frames p2p + all-gather of the GroupNorm partials), one "
-                              "hidden-token all-gather per temporal attention, CFG pair and final latents all-gathers; trunk || "
-                              "encoder enqueued in lockstep on two streams; VAE chunks round-robin")}[mode]
+                              "hidden-token all-gather per temporal attention, CFG pair and final latents all-gathers; " +
+                              ("trunk || encoder enqueued in lockstep on two streams" if getattr(pipe.parallel, "two_streams", False)
+                               else "trunk then encoder on one stream (MOFA_SHARD_TWO_STREAMS=1 opts into the lockstep two-stream order)") +
+                              "; VAE chunks round-robin")}[mode]
         line = {
             "metric": (f"denoised frames/sec, 25f 576x1024 SVD+MOFA, {STEPS} steps" if cfg != 5 else
                        f"denoised frames/sec, 97f (4 x 25f windows) 576x1024 SVD+MOFA hybrid, {STEPS} steps") +

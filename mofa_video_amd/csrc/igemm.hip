@@ -30,7 +30,7 @@
 // MOFA_IGEMM_CFG=2|4|5 forces the 128x128 | 192x128 | 256x256 phase-pipelined (igemm8.hip) tile for every launch that
 // leaves `tile` at 0.
 // Earlier variants (register staging, 64-byte rows, deeper rings, 256x128 tiles) and their measurements:
-// profiles/r01_igemm_config_sweep.md.
+// profiles/archive/r01_igemm_config_sweep.md.
 #include <stdlib.h>
 
 #include "igemm_common.h"
@@ -552,17 +552,17 @@ extern "C" int mofa_igemm_f16(const mofa_igemm_args* a, mofa_stream_t stream) {
         if (kind != 7) {
             // 256x320 (igemm320.hip): 0.58 per area (10 % less LDS-DMA, 7 % fewer fragment reads per flop than 256x256); its
             // epilogues move 25 % more outputs per tile
-            static const double epi320[9] = {3.0, 7.5, 8.5, 9.5, 3.5, 7.9, 9.0, 12.0, 5.0};   // fitted: profiles/r03_igemm_tiles_bench.log; r04: the
+            static const double epi320[9] = {3.0, 7.5, 8.5, 9.5, 3.5, 7.9, 9.0, 12.0, 5.0};   // fitted: profiles/archive/r03_igemm_tiles_bench.log; r04: the
             // residual kinds [1] [2] [3] [5] [6] lowered by 1.5-2 with the fp16-transposed residual epilogue (profiles/r04_res16_tiles_ab.log);
             // [1], [5] lowered from 10.0 / 10.5 in r03c so that the K = N = 320 residual launches leave the 192x128 tile (alone a
-            // draw: 352-414 against 372-403 TF/s by box; in the clip - 0.27 %, profiles/r03c_cost_model_and_splitk_ab.log:
+            // draw: 352-414 against 372-403 TF/s by box; in the clip - 0.27 %, profiles/archive/r03c_cost_model_and_splitk_ab.log:
             // beside a second stream the 17 % of padded columns of 3 x 128 are no longer free)
             const long long t = (long long)cdiv(a->M, 256) * cdiv(a->N, 320);
             // a partial last round split along K (igemm320_split) costs 1 / S of a round + the fix-up pass
             const int S = kind == 8 ? 1 : igemm320_split(t, (int)nk, n_cu, a->workspace ? a->workspace_bytes : 0);
             const double rounds = S > 1 ? (double)(t / n_cu) + 1.0 / S + 0.12 : (double)((t + n_cu - 1) / n_cu);
             // wide outputs (many column tiles: every CU of an XCD streams its own weight tile through the fabric) run
-            // relatively slower on this tile than on 256x256 (profiles/r03_igemm_tiles_bench_geglu320.log: N = 3840 / 10240
+            // relatively slower on this tile than on 256x256 (profiles/archive/r03_igemm_tiles_bench_geglu320.log: N = 3840 / 10240
             // 7 / 15 % behind): +2 % per column tile beyond 6, at most +25 %
             const int tn320 = cdiv(a->N, 320);
             const double wide = 1.0 + (tn320 > 6 ? (tn320 - 6 > 12 ? 0.25 : 0.02 * (tn320 - 6)) : 0.0);

@@ -17,7 +17,7 @@
 //     registers and refilled in the NEXT phase: phase 0 issues plane 1 of K tile t + 1, phase 1 issues plane 0 of K tile
 //     t + 2 -- 4 or 5 DMA pieces per wave and phase (9 per K tile; waves 0-3 take the ring's 4 odd W pieces in plane 0,
 //     waves 4-7 in plane 1), each with one K tile of flight before the counted wait `vmcnt(9)`.  A DMA piece is 16 rows x
-//     64 B (tools/dmabench.hip, profiles/r03_dmabench.log: up to 5 such half-line pieces per phase hide completely behind
+//     64 B (tools/dmabench.hip, profiles/archive/r03_dmabench.log: up to 5 such half-line pieces per phase hide completely behind
 //     20 MFMAs of the partner wave; 6 do not).  64-byte rows: the 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3)
 //     (applied to the DMA source address and to the fragment read; tools/lds_bank_sim.py: conflict-free).
 //   * bias (and the row vector when the wave's 64 rows share one row of it: every tile that does not straddle a frame) is
@@ -40,7 +40,7 @@ constexpr int RBH = 64;                                        // bytes of one K
 constexpr int XPL = TBM3 * RBH;                                // X part of a plane (16 KB)
 // NJ = accumulator column tiles per wave: 5 -> the 256x320 tile (shipped).  NJ = 4 (a 256x256 tile with the same K-half
 // schedule, incl. the GEGLU pair epilogue below) was built and measured in round 3 and is NOT instantiated: it is 5-10 %
-// SLOWER than igemm8.hip's X-row split on every shape (profiles/r03_igemm_tiles_bench_with_ksplit256.log: GEGLU L0 / L1 / L2
+// SLOWER than igemm8.hip's X-row split on every shape (profiles/archive/r03_igemm_tiles_bench_with_ksplit256.log: GEGLU L0 / L1 / L2
 // 750 / 920 / 1039 against 833 / 1017 / 1141 TF/s) -- the 256x320 tile's advantage is its shape (load segment of 14 reads
 // + 4.5 DMA pieces under 640 MFMA cycles; 256x256: 12 + 4 under 512), not the K-half split.
 template <int NJ> struct Geo {
@@ -1015,7 +1015,7 @@ int igemm320_split(long long T, int nk, int n_cu, long long ws_bytes) {
                                                                // of >= 4 K tiles changes nothing on the per-rank shapes of an
                                                                // 8-GPU run: mix 691 against 693 TF/s, profiles/r04_shard_shapes_tiles.log)
     // ... only where it pays: a slice saves (1 - 1 / S) of a tile's K loop (about 2 us per K tile) but costs the partial-tile
-    // dump and the fix-up launch (about 25 us; profiles/r03b_kernel_stats_bench.md: splitting the shallow-K launches of the
+    // dump and the fix-up launch (about 25 us; profiles/archive/r03b_kernel_stats_bench.md: splitting the shallow-K launches of the
     // clip -- 5 100 of 12 012 -- made it 4 % SLOWER)
     if (s >= 2 && 2.0 * nk * (1.0 - 1.0 / (double)s) < 50.0) s = 1;
     const long long per = (long long)TBM3 * Geo<5>::TBN * 4;

@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc FETCH_SIZE  --kernel-trace --output-format csv -d /tmp/tc_f -- python tools/traffic_classes.py run
     rocprofv3 --pmc WRITE_SIZE  --kernel-trace --output-format csv -d /tmp/tc_w -- python tools/traffic_classes.py run
-    python tools/traffic_classes.py report /tmp/tc_f /tmp/tc_w > profiles/r03_traffic_classes.md
+    python tools/traffic_classes.py report /tmp/tc_f /tmp/tc_w > profiles/archive/r03_traffic_classes.md
 
 ``run`` launches every (class, tile) case ITERS times in a fixed order and nothing else from libmofa_hip.so; ``report``
 matches the per-dispatch counter rows to the cases by that order and prints, per case, FETCH_SIZE and WRITE_SIZE in bytes
