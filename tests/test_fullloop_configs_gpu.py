@@ -12,7 +12,10 @@ tests/test_fullgeom_gpu.py: MIOpen off, exact chunked attention), same seeded we
             (25,49), hybrid control in every window, ``LONG_STEPS`` = 8 steps with the ``_step_index`` rewind and the overlap
             average after every step, against ``denoise_keypoint_loop(drag_controlnet=...)``; merged latents after every
             step and the decoded frames of the first and the last chunk (the VAE is per-chunk; all 7 chunks in the product).
-  world 8   config 2 on the BASELINE layout (2-way CFG x 4 frame shards of 7/6/6/6) as eight virtual ranks, 10 steps.
+  world 8   config 2 on the BASELINE layout (2-way CFG x 4 frame shards of 7/6/6/6) as eight virtual ranks, 10 steps; config 4
+            (Hybrid) on the same 8-rank layout for all 25 steps ("frames sharded over 8 x MI355X", BASELINE configs[3]).
+  config 5  at its FULL length: 97 frames, 7 distinct windows + the repeated last view, 2 steps, on one GPU and with the windows
+            dealt to 8 and 4 virtual ranks incl. the sharded / overlapped VAE decode (BASELINE configs[4]).
 
 The oracle's repeated views are served from the first evaluation of the same view in the same step
 (``reuse_identical_views``: the networks are deterministic functions of identical inputs; Euler step, rewind and merge still
@@ -124,18 +127,30 @@ def _keeper(keep):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+HYBRID_SCALES = dict(ctrl_scale_traj=0.8, ctrl_scale_ldmk=1.1)
+
+
+def _hybrid_trace(world):
+    """the oracle's Hybrid loop (config 4), latents after every step; computed once per module"""
+    if "trace4" not in world:
+        from oracle.pipeline import denoise_hybrid
+        from oracle.scheduler import EulerDiscreteScheduler as OSch
+        inp, ora = world["inp4"], world["ora"]
+        with exact_fp32_gpu():
+            (_, trace), sec = _timed(lambda: denoise_hybrid(
+                ora["unet"], ora["ldmk"], ora["cn"], OSch(), inp["latents"], world["il2"], world["emb2"], inp["cond"], inp["flow"],
+                inp["landmarks"], inp["drag_flow"], inp["mask"], num_inference_steps=STEPS, return_trace=True, **HYBRID_SCALES))
+        print(f"oracle (Hybrid) on the GPU in fp32: {STEPS} steps at {T} f {H}x{W} in {sec:.1f} s")
+        world["trace4"] = trace
+    return world["trace4"]
+
+
 def test_config4_hybrid_full_loop_vs_oracle(world):
     from mofa_video_amd.pipeline import HybridFlowControlNetPipeline
     from mofa_video_amd.scheduler import EulerDiscreteScheduler
-    from oracle.pipeline import denoise_hybrid
-    from oracle.scheduler import EulerDiscreteScheduler as OSch
-    inp, hip, ora = world["inp4"], world["hip"], world["ora"]
-    scales = dict(ctrl_scale_traj=0.8, ctrl_scale_ldmk=1.1)
-    with exact_fp32_gpu():
-        (_, trace), sec = _timed(lambda: denoise_hybrid(
-            ora["unet"], ora["ldmk"], ora["cn"], OSch(), inp["latents"], world["il2"], world["emb2"], inp["cond"], inp["flow"],
-            inp["landmarks"], inp["drag_flow"], inp["mask"], num_inference_steps=STEPS, return_trace=True, **scales))
-    print(f"oracle (Hybrid) on the GPU in fp32: {STEPS} steps at {T} f {H}x{W} in {sec:.1f} s")
+    inp, hip = world["inp4"], world["hip"]
+    scales = HYBRID_SCALES
+    trace = _hybrid_trace(world)
     pipe = HybridFlowControlNetPipeline(vae=hip["vae"], unet=hip["unet"], face_controlnet=hip["ldmk"], drag_controlnet=hip["cn"],
                                         scheduler=EulerDiscreteScheduler())
     keep = {}
@@ -280,3 +295,123 @@ def test_world8_baseline_layout_10_steps_vs_oracle(world):
         worst = max(worst, e_all, *errs.values(), *upd.values())
     assert sizes[:4] == [7, 6, 6, 6], sizes
     assert worst < TOL, worst
+
+
+def _virtual_ranks(nranks, fn):
+    """fn(rank, thread_world) on ``nranks`` threads of this process sharing the GPU"""
+    from mofa_video_amd.parallel import ThreadWorld
+    tw = ThreadWorld(nranks)
+    results, errors = [None] * nranks, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            results[r] = fn(r, tw)
+        except Exception as e:  # noqa: BLE001
+            errors.append((r, repr(e)))
+            for b in tw.barriers.values():
+                b.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(1800)
+    assert not errors, errors
+    return results
+
+
+def test_config4_hybrid_frames_sharded_over_8_ranks_vs_oracle(world):
+    """BASELINE config 4 as it is worded: the Hybrid dual-adapter clip with its frames sharded over 8 ranks (2-way CFG x 4 frame
+    shards of 7 / 6 / 6 / 6; both adapters warp and step only the rank's frames, the mask blend is per frame), all ``STEPS`` steps,
+    every rank's shard after the marked steps and the gathered clip against the oracle's Hybrid loop"""
+    from mofa_video_amd.parallel import FrameParallel, Layout, ThreadComm
+    from mofa_video_amd.pipeline import HybridFlowControlNetPipeline
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    inp, hip = world["inp4"], world["hip"]
+    trace = _hybrid_trace(world)
+    nranks = 8
+    keeps = [dict() for _ in range(nranks)]
+
+    def run(r, tw):
+        pipe = HybridFlowControlNetPipeline(vae=hip["vae"], unet=hip["unet"], face_controlnet=hip["ldmk"], drag_controlnet=hip["cn"],
+                                            scheduler=EulerDiscreteScheduler(),
+                                            parallel=FrameParallel(Layout(nranks, r, T), ThreadComm(tw, r)))
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=inp["landmarks"],
+                    drag_flow=inp["drag_flow"], mask=inp["mask"], height=H, width=W, num_frames=T, num_inference_steps=STEPS,
+                    decode_chunk_size=bench.CHUNK, latents=inp["latents"], output_type="latent",
+                    callback_on_step_end=_keeper(keeps[r]), image_embeddings=world["emb2"], image_latents=world["il2"],
+                    **HYBRID_SCALES).frames
+    outs = _virtual_ranks(nranks, run)
+    x0 = _x0(inp["latents"], STEPS)
+    worst = 0.0
+    for r in range(nranks):
+        lay = Layout(nranks, r, T)
+        errs, upd = report(f"config 4 (Hybrid), world {nranks} rank {r} (half {lay.half}, frames {lay.f0}..{lay.f1 - 1})", keeps[r], trace,
+                           x0, STEPS, slice(lay.f0, lay.f1))
+        e_all = rel(outs[r], trace[-1])
+        print(f"config 4 (Hybrid), world {nranks} rank {r}: gathered clip after {STEPS} steps rel-L2 {e_all:.3e} vs oracle")
+        worst = max(worst, e_all, *errs.values(), *upd.values())
+    assert worst < TOL, worst
+
+
+def test_config5_full_length_97_frames_single_gpu_and_8_ranks_vs_oracle(world):
+    """BASELINE config 5 at its full length: 97 frames = 7 distinct windows of 25 (stride 12) + the repeated last view, hybrid
+    control in every window, 576x1024, full width, ``FULL_STEPS`` steps -- on one GPU, and with the windows dealt to 8 and to 4
+    ranks (``parallel.WindowParallel``; 4 ranks = two rounds: the decode of finished chunks overlaps the second round of the last
+    step on a second stream), latents and the first / last decoded chunks against the oracle"""
+    from mofa_video_amd.parallel import ThreadComm, WindowParallel
+    from mofa_video_amd.pipeline import KeypointFlowControlNetPipeline, window_views
+    from mofa_video_amd.scheduler import EulerDiscreteScheduler
+    from oracle.pipeline import denoise_keypoint_loop
+    from oracle.scheduler import EulerDiscreteScheduler as OSch
+    hip, ora = world["hip"], world["ora"]
+    N, steps = bench.LONG_FRAMES, int(os.environ.get("MOFA_FULLLOOP_FULL_STEPS", "2"))
+    inp = bench.config_inputs(torch.device(DEV), 5)
+    views = window_views(N, T, T // 2)
+    assert N == 97 and len(set(views)) == 7 and len(views) == 8, views
+    kw = dict(ctrl_scale_traj=0.9, controlnet_cond_scale=1.05)
+    with exact_fp32_gpu():
+        (_, trace), sec = _timed(lambda: denoise_keypoint_loop(
+            ora["unet"], ora["ldmk"], OSch(), inp["latents"], world["il2"], world["emb2"], inp["cond"], inp["flow"],
+            inp["landmarks"], window_size=T, stride=T // 2, num_inference_steps=steps, drag_controlnet=ora["cn"],
+            drag_flow=inp["drag_flow"], mask=inp["mask"], return_trace=True, reuse_identical_views=True, **kw))
+    print(f"oracle (window loop, hybrid control) on the GPU in fp32: {len(views)} views, {steps} steps at {N} f {H}x{W} in {sec:.1f} s")
+    last0 = (N - 1) // bench.CHUNK * bench.CHUNK
+    ref = _oracle_frames(world, trace[-1], [(0, bench.CHUNK), (last0, N)])
+
+    def run(parallel, output_type, keep=None):
+        pipe = KeypointFlowControlNetPipeline(vae=hip["vae"], unet=hip["unet"], controlnet=hip["ldmk"], drag_controlnet=hip["cn"],
+                                              scheduler=EulerDiscreteScheduler(), parallel=parallel)
+        return pipe(None, controlnet_condition=inp["cond"], controlnet_flow=inp["flow"], landmarks=inp["landmarks"],
+                    window_size=T, stride=T // 2, height=H, width=W, num_frames=N, num_inference_steps=steps,
+                    decode_chunk_size=bench.CHUNK, latents=inp["latents"], output_type=output_type,
+                    callback_on_step_end=_keeper(keep) if keep is not None else None, image_embeddings=world["emb2"],
+                    image_latents=world["il2"], drag_flow=inp["drag_flow"], mask=inp["mask"], **kw).frames
+    # one GPU
+    keep = {}
+    frames = run(None, "raw", keep)
+    errs, upd = report(f"config 5 at full length, {steps} steps @ {N}f {H}x{W}, one GPU", keep, trace, _x0(inp["latents"], steps), steps)
+    ef = max(rel(frames[:, :, s0:s1], v) for (s0, s1), v in ref.items())
+    print(f"config 5 at full length, one GPU: decoded frames 0..{bench.CHUNK - 1} and {last0}..{N - 1} rel-L2 vs oracle {ef:.3e}")
+    assert max(errs.values()) < TOL and max(upd.values()) < TOL and ef < TOL, (errs, max(upd.values()), ef)
+    del frames
+    # windows dealt to 8 ranks (the BASELINE layout: one round, one rank idle in the loop) and to 4 (two rounds, overlapped decode)
+    for nranks in (8, 4):
+        lat = _virtual_ranks(nranks, lambda r, tw: run(WindowParallel(ThreadComm(tw, r), r, nranks), "latent"))
+        e_lat = max(rel(o, trace[-1]) for o in lat)
+        assert all(torch.equal(o, lat[0]) for o in lat), "ranks disagree on the merged latents"
+        del lat
+        chunks = _virtual_ranks(nranks, lambda r, tw: run(WindowParallel(ThreadComm(tw, r), r, nranks), "raw"))
+        owner, ef = {}, 0.0
+        for r, mine in enumerate(chunks):
+            for s0, fr in mine:                                              # fr [n, 3, H, W]
+                assert s0 not in owner, (s0, r, owner)
+                owner[s0] = r
+                for (a, b), v in ref.items():
+                    if a == s0:
+                        ef = max(ef, rel(fr.permute(1, 0, 2, 3).unsqueeze(0), v))
+        assert sorted(owner) == list(range(0, N, bench.CHUNK)), owner
+        print(f"config 5 at full length, windows over {nranks} ranks: latents rel-L2 vs oracle {e_lat:.3e}, decoded first / last chunk "
+              f"{ef:.3e}; chunk -> rank {owner}")
+        del chunks
+        assert e_lat < TOL and 0.0 < ef < TOL, (nranks, e_lat, ef)

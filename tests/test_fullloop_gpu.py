@@ -9,7 +9,8 @@ oracle run (module fixture, latents kept after EVERY step) is compared with the 
   (a) the default order: adapter trunk || UNet encoder and the decoder's CFG halves on two HIP streams;
   (b) single-stream order (``overlap_adapter = False``; what ``bench.py --single-stream`` and the roofline leg run);
   (c) ``round_latents_to_fp16=True`` (the reference's fp16 run rounds the latents after every step, scheduling_...:520)
-      -- against the fp32 oracle AND against the oracle with the same rounding;
+      -- against the fp32 oracle (and, with MOFA_FULLLOOP_ORACLE_FP16=1, against the oracle with the same rounding: a second
+      oracle run, profiles/r04_fullloop.log);
   (d) the frame-sharded layout, world 4 (2-way CFG x 2 frame shards) as virtual ranks on this GPU, every rank's shard after
       every step and the gathered clip at the end: sharded-vs-single, kernel-vs-oracle and 25 steps of error growth are spent
       against ONE tolerance here.
@@ -80,7 +81,7 @@ def world():
                            return_trace=True)
         ev1.record()
         trace16 = None
-        if os.environ.get("MOFA_FULLLOOP_ORACLE_FP16", "1") == "1":
+        if os.environ.get("MOFA_FULLLOOP_ORACLE_FP16", "0") == "1":   # (a second 90 s oracle run: opt-in since r05, recorded in profiles/r04_fullloop.log)
             _, trace16 = denoise(ou, oc, _RoundingScheduler(OSch()), inp["latents"], il2, emb2, inp["cond"], inp["flow"],
                                  num_inference_steps=STEPS, return_trace=True)
         del ou, oc

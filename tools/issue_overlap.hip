@@ -9,7 +9,7 @@
 //   3  interleaved: (1 MFMA, 5 VALU) x 32            (software-pipelined order)
 //   4  half-blocked: 8 MFMA, 40 VALU, ... x 4
 // run with 4 waves per CU (1 per SIMD) and 8 (2 per SIMD; 512-thread workgroups or two 256-thread workgroups).
-// build: hipcc --offload-arch=gfx950 -O3 tools/issue_overlap.hip -o tools/issue_overlap.bin
+// build + run ON the GPU box (binaries do not travel with gpurun): hipcc --offload-arch=gfx950 -O3 tools/issue_overlap.hip -o /tmp/io.bin && /tmp/io.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
