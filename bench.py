@@ -3,9 +3,9 @@
 on N MI355X (BASELINE.json metric; config[1] "MOFA-Video-Traj, 25-frame 576x1024, 25 steps, single trajectory
 hint").
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: spawns the N ranks itself (spawn_ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             # the same job under the driver's launcher (WORLD_SIZE must equal N)
 
 One "step" = one whole clip, the reference pipeline call from the conditioning image to the frames: image conditioning
 (antialiased resize + CLIP ViT-H/14 image encoder, noise augmentation + VAE encoder; once per clip, < 1 % of the time) +
@@ -356,6 +356,31 @@ def cpu_baseline(timeout=420):
                         f"25 / {clip_s:.0f} s"))
 
 
+def spawn_command(n, argv, port):
+    """The command line `python bench.py --gpus N ...` re-executes itself under: one process per GPU, torch.distributed.run on
+    the loopback address (the driver's own launch line for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks here and pass rank 0's single JSON
+    line through.  Fewer than N visible GPUs is an error -- never a fall-back to one GPU -- unless MOFA_BENCH_ONE_GPU=1
+    (functional check of the multi-process path: all ranks on GPU 0, use --backend gloo)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("MOFA_BENCH_ONE_GPU") != "1":
+        raise SystemExit(f"bench.py: --gpus {n} requested but {have} GPU(s) visible; refusing to run a smaller job under an "
+                         f"{n}-GPU command (MOFA_BENCH_ONE_GPU=1 --backend gloo runs the {n}-process path on one GPU as a functional check)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    return subprocess.call(spawn_command(n, argv, port), env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,9 +417,14 @@ def main():
         print(json.dumps(cpu_baseline_full()))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))    # plain `python bench.py --gpus N`: N ranks, never a silent 1-GPU run
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         "(or plain `python bench.py --gpus N`, which spawns the ranks itself)")
     dist = None
     if world > 1:
         import torch.distributed as dist

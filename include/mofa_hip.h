@@ -42,6 +42,10 @@ int mofa_version(void);
  * Implicit-GEMM on MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate).
  *   out[m, n] = act( s_acc * (sum_{tap,k} X[src(m,tap), k] * W[n, tap*Cin + k] + bias[n] + rowvec[idx(m), n])
  *                    + s1 * R1[m, n] + s2 * R2[m, n] )
+ * Rounding: fp32 accumulate; WITH a residual (R1 or R2) the term s_acc * (...) is rounded to fp16 before the residuals are added
+ * in fp32 and the sum is rounded once more -- the reference's fp16 modules produce the layer's output in fp16 and then add --;
+ * without residuals there is one rounding.  Every tile kernel rounds this way, so the tile choice never changes the bits of an
+ * exactly representable sum (tests/test_igemm_tiles_gpu.py::test_all_tiles_round_residual_adds_alike).
  * Replaces every nn.Linear / nn.Conv2d(1x1, 3x3 s1/s2, nearest-2x + 3x3) / nn.Conv3d((3,1,1))
  * the reference reaches through diffusers blocks (ResnetBlock2D, TemporalResnetBlock,
  * Downsample2D, Upsample2D, Attention.to_q/k/v/out, FeedForward; built at

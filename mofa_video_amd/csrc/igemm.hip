@@ -220,6 +220,7 @@ __device__ __forceinline__ void igemm_epilogue(const mofa_igemm_args& a, f32x16 
                         float x0 = v[e] + bias[0][e], x1 = v[4 + e] + bias[1][e];
                         if (RV) { x0 += L[pg].rv0[e]; x1 += L[pg].rv1[e]; }
                         x0 *= saccv; x1 *= saccv;
+                        if (R1 || R2) { x0 = (float)(f16)x0; x1 = (float)(f16)x1; }   // fp16 before the residual add, on every tile kernel
                         if (R1) { x0 += s1v * (float)L[pg].t1[e]; x1 += s1v * (float)L[pg].t1[4 + e]; }
                         if (R2) { x0 += s2v * (float)L[pg].t2[e]; x1 += s2v * (float)L[pg].t2[4 + e]; }
                         v[e] = x0; v[4 + e] = x1;

@@ -505,6 +505,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_f16_kernel(const mofa_igemm_arg
                     float x0 = v0[e] + bv[j][0][e], x1 = v1[e] + bv[j][1][e];
                     if (RV && !UNI) { x0 += l.rv0[p][e]; x1 += l.rv1[p][e]; }
                     x0 *= saccv; x1 *= saccv;
+                    // (the layer's own output is rounded to fp16 BEFORE a residual add on every tile kernel, like the
+                    //  reference's fp16 modules and igemm320's epilogue_res16: the tile choice never changes the bits)
+                    if (R1 || R2) { x0 = (float)(f16)x0; x1 = (float)(f16)x1; }
                     if (R1) { x0 += s1v * (float)l.t1[p][e]; x1 += s1v * (float)l.t1[p][4 + e]; }
                     if (R2) { x0 += s2v * (float)l.t2[p][e]; x1 += s2v * (float)l.t2[p][4 + e]; }
                     o[e] = (f16)x0; o[4 + e] = (f16)x1;

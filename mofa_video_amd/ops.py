@@ -215,13 +215,21 @@ def igemm(x, w, bias=None, geom=PLAIN, M=None, rowvec=None, rv=(1, 1, 1, 1 << 30
         TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * Ktot,
                    tag=(mode, geom.stride, geom.up, M, N, Ktot, act))
     if st is not None:
-        out.gn_stats = (st, out._version, out.data_ptr())     # (group_norm ignores them if torch saw an in-place write since)
+        out.gn_stats = (st, _version(out), out.data_ptr())    # (group_norm ignores them if torch saw an in-place write since)
+    elif not fresh:
+        _written(out)
     return out
+
+
+def _version(t):
+    """torch's in-place write counter, or -1 for a tensor that keeps none (created under ``torch.inference_mode()``: reading
+    ``_version`` raises there) -- such a tensor is guarded by its data pointer and this module's ``_written`` calls only"""
+    return -1 if t.is_inference() else t._version
 
 
 def _written(t):
     """an entry point of this module is about to write ``t`` in place: pair sums a producer attached describe the old values"""
-    if getattr(t, "gn_stats", None) is not None:
+    if t is not None and getattr(t, "gn_stats", None) is not None:
         del t.gn_stats
 
 
@@ -240,7 +248,7 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
     pairs = getattr(x, "gn_stats", None)                      # pair sums the producing igemm epilogue emitted (igemm(stats=True))
     if pairs is not None:                                     # ... valid only for the very tensor object / values the producer left
         pairs, ver, dptr = pairs
-        if ver != x._version or dptr != x.data_ptr():
+        if ver != _version(x) or dptr != x.data_ptr():
             pairs = None
     if pairs is not None and HW % 64 == 0 and Cc % 64 == 0 and tuple(pairs.shape) == (nframes * HW // 64, Cc) == (x.shape[0] // 64, x.shape[1]):
         L.check(lib.mofa_gn_partial_from_stats(L.ptr(pairs), L.ptr(part), nframes, HW, Cc, st), "mofa_gn_partial_from_stats")
@@ -249,6 +257,8 @@ def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, 
         L.check(lib.mofa_gn_partial_f16(L.ptr(x), L.ptr(part), nframes, HW, Cc, _ld(x), st), "mofa_gn_partial_f16")
     if out is None:
         out = torch.empty((x.shape[0], Cc), dtype=F16, device=x.device)
+    else:
+        _written(out)
     if frames_per_stat * nparts <= GN_FUSED_MAX_ENTRIES:
         # two launches: the applying kernel combines the partial sums of its statistics set itself
         L.check(lib.mofa_gn_apply_f16(L.ptr(x), L.ptr(part), L.ptr(gamma), L.ptr(beta), L.ptr(out), nframes, HW, Cc, _ld(x),
@@ -284,6 +294,7 @@ def gn_apply_gathered(x, part_all, count_per_group, gamma, beta, eps, out, nfram
     lib = L.load()
     _chk(x, F16); _chk(out, F16); _chk(part_all, F32)
     assert x.shape[0] == nframes * HW == out.shape[0] and part_all.is_contiguous()
+    _written(out)
     L.check(lib.mofa_gn_apply_gathered_f16(L.ptr(x), L.ptr(part_all), part_all.shape[0], float(count_per_group), L.ptr(gamma),
                                            L.ptr(beta), L.ptr(out), nframes, HW, x.shape[1], _ld(x), _ld(out), eps,
                                            1 if silu else 0, L.stream_ptr()), "mofa_gn_apply_gathered_f16")
@@ -296,6 +307,8 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
     M, Cc = x.shape
     if out is None:
         out = torch.empty((M, Cc), dtype=F16, device=x.device)
+    else:
+        _written(out)
     L.check(lib.mofa_layernorm_f16(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(out), M, Cc, _ld(x), _ld(out), eps,
                                    L.ptr(rowvec), rv_div, rv_mod, L.stream_ptr()), "mofa_layernorm_f16")
     return out
@@ -315,6 +328,8 @@ def attn_spatial(q, k, v, nframes, heads, S, head_dim=64, scale=None, out=None, 
     st = L.stream_ptr()
     if out is None:
         out = torch.empty((nframes * S, Cc), dtype=F16, device=q.device)
+    else:
+        _written(out)
     t0 = TIMER.start() if TIMER is not None else None
     L.check(lib.mofa_attn_spatial_qb_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nframes, heads, head_dim, S, _ld(q),
                                          _ld(k), _ld(v), _ld(out), scale, int(query_blocks), st), "mofa_attn_spatial_qb_f16")
@@ -332,6 +347,8 @@ def attn_temporal(q, k, v, nclips, T, HW, heads, head_dim=64, scale=None, out=No
     scale = head_dim ** -0.5 if scale is None else scale
     if out is None:
         out = torch.empty((nclips * Tq * HW, heads * head_dim), dtype=F16, device=q.device)
+    else:
+        _written(out)
     if key_mask is None:
         L.check(lib.mofa_attn_temporal_f16(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(out), nclips, Tq, T, HW, heads, head_dim,
                                            _ld(q), _ld(k), _ld(out), scale, L.stream_ptr()), "mofa_attn_temporal_f16")
@@ -404,6 +421,8 @@ def mask_blend(a, b, w, HW, out=None):
     assert a.shape == b.shape
     if out is None:
         out = torch.empty(a.shape, dtype=F16, device=a.device)
+    else:
+        _written(out)
     L.check(lib.mofa_mask_blend_f16(L.ptr(a), L.ptr(b), L.ptr(w), L.ptr(out), a.shape[0], a.shape[1], HW, _ld(a), _ld(b),
                                     _ld(out), L.stream_ptr()), "mofa_mask_blend_f16")
     return out
@@ -426,6 +445,8 @@ def geglu(x, out=None):
     Ch = C2 // 2
     if out is None:
         out = torch.empty((M, Ch), dtype=F16, device=x.device)
+    else:
+        _written(out)
     L.check(lib.mofa_geglu_f16(L.ptr(x), L.ptr(out), M, Ch, _ld(x), _ld(out), L.stream_ptr()), "mofa_geglu_f16")
     return out
 
@@ -433,6 +454,7 @@ def geglu(x, out=None):
 def copy2d(src, dst):
     lib = L.load()
     assert src.shape == dst.shape
+    _written(dst)
     L.check(lib.mofa_copy2d_f16(L.ptr(src), L.ptr(dst), src.shape[0], src.shape[1], _ld(src), _ld(dst), L.stream_ptr()),
             "mofa_copy2d_f16")
     return dst
@@ -489,6 +511,7 @@ def nchw_to_tokens(x, ld=None, scale=1.0, out=None):
     n, Cc, H, W = x.shape
     if out is not None:
         assert out.shape[0] == n * H * W and out.shape[1] >= Cc
+        _written(out)
         L.check(lib.mofa_nchw_f32_to_nhwc_f16(L.ptr(x.contiguous()), L.ptr(out), n, Cc, H * W, _ld(out), float(scale),
                                               L.stream_ptr()), "mofa_nchw_f32_to_nhwc_f16")
         return out
@@ -662,6 +685,7 @@ def pool2d(x, nimg, H, W, C, k, stride, pad=0, mode="max", out=None):
     if out is None:
         out = torch.empty((nimg * Ho * Wo, C), dtype=F16, device=x.device)
     assert x.shape[0] == nimg * H * W and out.shape[0] == nimg * Ho * Wo
+    _written(out)
     L.check(lib.mofa_pool2d_f16(L.ptr(x), L.ptr(out), nimg, H, W, C, _ld(x), _ld(out), k, stride, pad, 0 if mode == "max" else 1,
                                 L.stream_ptr()), "mofa_pool2d_f16")
     return out, Ho, Wo
@@ -674,6 +698,7 @@ def resize_bilinear_ac(x, nimg, H, W, C, Ho, Wo, out=None):
     if out is None:
         out = torch.empty((nimg * Ho * Wo, C), dtype=F16, device=x.device)
     assert x.shape[0] == nimg * H * W and out.shape[0] == nimg * Ho * Wo
+    _written(out)
     L.check(lib.mofa_resize_bilinear_ac_f16(L.ptr(x), L.ptr(out), nimg, H, W, Ho, Wo, C, _ld(x), _ld(out), L.stream_ptr()),
             "mofa_resize_bilinear_ac_f16")
     return out

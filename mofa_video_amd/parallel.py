@@ -296,7 +296,9 @@ class FrameParallel:
         self.gather_hidden = True   # ... of the normed hidden tokens (C columns; K|V projected after the gather) instead of K|V (2C)
         # adapter trunk || UNet encoder on two HIP streams, enqueued layer by layer in lockstep: the transport's default (on for
         # the in-process ThreadComm; OFF for TorchComm until an N-GPU RCCL run has been recorded, MOFA_SHARD_TWO_STREAMS=1)
-        self.two_streams = getattr(comm, "two_streams_default", True)
+        # Derived from THIS communicator (round-5 advice): a TorchComm built with one communicator set per group must never run
+        # the lockstep order (both networks would share bulk / ctl / data), one built with two lanes runs it.
+        self.two_streams = bool(getattr(comm, "two_lanes", getattr(comm, "two_streams_default", True)))
         self.split_convs = False    # (3,1,1) convolutions as interior + boundary launches while the halo frames travel: OFF --
                                     # on the 1-GPU proxy of a rank of 8 the extra launches cost 3.1 ms of a 49 ms step while
                                     # all halo frames of a step are <= 2.5 ms of wire time that the second network already
@@ -371,6 +373,9 @@ class FrameParallel:
         # --- two networks in lockstep on two streams: one exchange group (partials, halo, tokens) of lane 0 on a side stream
         # interleaved with lane 1's on the caller's stream, in the order run_lockstep issues them; wrong data or an exception
         # switches the overlap off on every rank of the group (a hang cannot be caught here: see above)
+        if self.two_streams and getattr(self.comm, "two_lanes", True) is False:
+            self.two_streams = False                       # set by hand on a one-lane communicator: not a supported combination
+            report["order_note"] = "two_streams requested on a one-lane communicator: switched off"
         report["order"] = "two streams, lockstep" if self.two_streams else "one stream"
         if self.two_streams:
             ok = 1.0

@@ -68,7 +68,10 @@ def check_frame_exchanges(rank, world, T, HW, C, device):
     # own bulk / ctl / data communicators and the self-check exercises one interleaved exchange group on both of them
     assert not par.two_streams and rep["order"] == "one stream", rep
     par2 = FrameParallel(lay, TorchComm(lambda r: Layout(world, r, T, cfg_ranks=1), two_lanes=True))
-    par2.two_streams = True
+    assert par2.two_streams                                                # derived from the communicator's own two_lanes
+    par.two_streams = True                                                 # by hand on the ONE-lane communicator: refused
+    rep1 = par.self_check(device)
+    assert not par.two_streams and "order_note" in rep1, (rank, rep1)
     rep2 = par2.self_check(device)
     assert par2.two_streams and rep2["order"].startswith("two streams") and "order_error" not in rep2, (rank, rep2)
     orig_h = par2.halo_begin

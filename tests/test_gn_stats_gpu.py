@@ -149,6 +149,41 @@ def test_group_norm_from_stats(ops, C, HW, frames, fps, silu):
     assert torch.equal(fused, fused2), "not deterministic"
 
 
+def test_stats_under_inference_mode_and_out_writers(ops):
+    """round-5 advice (medium): tensors created under torch.inference_mode() keep no version counter -- reading ``_version``
+    raises -- so a caller who wraps the pipeline call in inference_mode crashed on the first GroupNorm-producer conv.  And (low):
+    every entry point of ops that writes a caller-supplied ``out`` drops pair sums attached to it."""
+    C, HW, frames = 320, 576, 4
+    x, w, bias = _h(frames * HW, 64, seed=31), _h(C, 64, seed=32, scale=0.2), _f(C, seed=33)
+    g, b = _f(C, seed=34), _f(C, seed=35)
+    want = ops.group_norm(ops.igemm(x, w, bias), g, b, frames, HW, 1e-5)
+    with torch.inference_mode():
+        y = ops.igemm(x, w, bias, stats=True)
+        assert y.is_inference() and getattr(y, "gn_stats", None) is not None
+        got = ops.group_norm(y, g, b, frames, HW, 1e-5)
+    d = (got.float() - want.float()).abs().max().item()
+    assert d <= 2e-3 * want.float().abs().max().item() + 2e-3, d
+    other = _h(frames * HW, C, seed=36)
+    writers = {
+        "igemm(out=)": lambda y: ops.igemm(x, w, bias, out=y),
+        "group_norm(out=)": lambda y: ops.group_norm(other, g, b, frames, HW, 1e-5, out=y),
+        "layer_norm(out=)": lambda y: ops.layer_norm(other, g, b, out=y),
+        "copy2d": lambda y: ops.copy2d(other, y),
+        "axpby_out": lambda y: ops.axpby_out(other, other, 0.5, 0.5, y),
+        "mask_blend(out=)": lambda y: ops.mask_blend(other, other, torch.rand(HW, device=DEV), HW, out=y),
+    }
+    for name, write in writers.items():
+        for inference in (False, True):
+            with (torch.inference_mode() if inference else torch.no_grad()):
+                y = ops.igemm(x, w * 3, bias, stats=True)              # sums of OTHER values than the writer leaves
+                assert getattr(y, "gn_stats", None) is not None
+                write(y)
+                assert getattr(y, "gn_stats", None) is None, f"{name}: stale pair sums kept (inference={inference})"
+                got = ops.group_norm(y, g, b, frames, HW, 1e-5)
+                ref = ops.group_norm(y.clone(), g, b, frames, HW, 1e-5)
+            assert torch.equal(got, ref), name
+
+
 def test_resblock_stats_switch(ops):
     """a SpatioTemporalResBlock + transformer norm with the epilogue-emitted sums against the same layers with ops.GN_STATS off"""
     from mofa_video_amd import blocks

@@ -321,6 +321,39 @@ def test_split_and_whole_tiles_round_alike(ops, kind):
     assert (whole.float() - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("kind", ["r1 s1=1", "r1 s1=0.5", "r1r2", "r1 + per-row row vector", "r1 + uniform row vector"])
+def test_all_tiles_round_residual_adds_alike(ops, kind):
+    """round-5 advice: the same layer must give the same bits whichever tile the cost model picks (the pick depends on shape, CU
+    count, workspace, sharded vs unsharded M).  Every tile kernel rounds s_acc * (acc + bias + rowvec) to fp16 BEFORE the residual
+    add (include/mofa_hip.h).  Operands exact in fp32 => summation order cannot matter => all four tiles agree bit for bit, and
+    with the literal double-rounding formula."""
+    M, N, K = 2309, 640, 512                                    # ragged M: tail rows on every tile height
+    g = torch.Generator(device=DEV).manual_seed(91)
+    x = torch.randint(-3, 4, (M, K), generator=g, device=DEV).half()
+    w = (torch.randint(-2, 3, (N, K), generator=g, device=DEV).float() / 16).half()
+    bias = torch.randint(-64, 65, (N,), generator=g, device=DEV).float() / 16
+    # residuals on a 2^-6 grid, |r| <= 8: x0 + s1 r1 + s2 r2 is exact in fp32 in any association
+    r1 = (torch.randint(-512, 513, (M, N), generator=g, device=DEV).float() / 64).half()
+    kw = dict(s_acc=0.75, r1=r1, s1=1.0)
+    if kind == "r1 s1=0.5":
+        kw["s1"] = 0.5
+    elif kind == "r1r2":
+        kw.update(r2=(torch.randint(-512, 513, (M, N), generator=g, device=DEV).float() / 64).half(), s2=0.25)
+    elif kind.endswith("row vector"):
+        rv = (1000, 3, 1, 5) if "uniform" in kind else (7, 3, 4, 5)
+        kw.update(rowvec=torch.randint(-64, 65, (5, N), generator=g, device=DEV).float() / 16, rv=rv)
+    acc = x.float() @ w.float().t() + bias
+    if "rowvec" in kw:
+        m = torch.arange(M, device=DEV)
+        d, mul, mi, mo = kw["rv"]
+        acc = acc + kw["rowvec"][((m // d) * mul + (m % mi)) % mo]
+    ref = ((0.75 * acc).half().float() + kw["s1"] * r1.float() + (kw["s2"] * kw["r2"].float() if "r2" in kw else 0.0)).half()
+    outs = {name: ops.igemm(x, w, bias, tile=t, split_k=False, **kw) for name, t in TILES.items()}
+    for name, o in outs.items():
+        dmax = (o.float() - ref.float()).abs().max().item()
+        assert torch.equal(o, ref), f"{kind}: tile {name} differs from round16(s_acc*acc) + residuals (max diff {dmax:.3e})"
+
+
 @pytest.mark.parametrize("mode", ["conv3x3", "conv3x3_s2", "convt3", "convt3_halo"])
 def test_split_k_convolutions_slices_start_inside_a_tap(ops, mode):
     """split-K on the implicit-GEMM convolutions: the K slices of a remainder tile start in the MIDDLE of a tap (9 or 3 taps of
