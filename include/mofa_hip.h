@@ -198,6 +198,42 @@ int mofa_layernorm_f16(const void* x, const float* gamma, const float* beta, voi
                        mofa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused feed-forward for 320-channel tokens (level 0 of the UNet / ControlNet): ONE launch for
+ *   LayerNorm -> GEGLU projection (320 -> 2 x 1280) -> value * gelu(gate) -> output projection (1280 -> 320) -> residuals
+ * i.e. the feed-forward legs of diffusers' BasicTransformerBlock (norm3 -> ff) and TemporalBasicTransformerBlock (norm_in -> ff_in,
+ * norm3 -> ff) as the reference builds them (models/unet_spatio_temporal_condition_controlnet.py:169-232,
+ * models/controlnet_sdv.py:259-309); replaces mofa_layernorm_f16 + two mofa_igemm_f16 launches and the [M, 1280] hidden tensor.
+ *   x'[m]   = x[m] + pos[(m / HW) % T]                                  (pos == NULL: x' = x)
+ *   out[m]  = f16( f16( s_acc * (W2 . (val * gelu_erf(gate)) + b2) ) + s1 * x'[m] + s2 * r2[m] ),
+ *             [val | gate] = W1 . LayerNorm_eps(x'[m]) + b1
+ *   out_ln[m] = LayerNorm_ln_eps(out[m]) * ln_gamma + ln_beta          (optional second output: the norm of the NEXT projection)
+ * Packed operands (mofa_video_amd/weights.py::pack_ff320 writes them; all index ranges below are inclusive-exclusive):
+ *   w1p  fp16 [40 chunks][2 (value, gate)][20 k-steps][64 lanes][8]: element e of lane l = W1g[t * 1280 + 32 c + (l & 31)]
+ *        [16 s + 8 (l >> 5) + e], W1g = net.0.proj.weight * LayerNorm gain (per input channel), rows [0,1280) value, [1280,2560) gate
+ *   b1   fp32 [2560] = net.0.proj.bias + net.0.proj.weight . LayerNorm bias                      (natural order)
+ *   w2p  fp16 [40 chunks][10 out tiles][2 k-steps][64 lanes][8]: element jj of lane l = net.2.weight[32 j + (l & 31)]
+ *        [32 c + 16 u + 4 (l >> 5) + (jj & 3) + 8 (jj >> 2)]
+ *   b2   fp32 [320]
+ * All pointers 16-byte aligned, ld* % 8 == 0.  fp16 MFMA, fp32 accumulation / LayerNorm / GELU / residual arithmetic. */
+typedef struct mofa_ff320_args {
+    const void* x;          /* fp16 [M][ldx]                                    */
+    const float* pos;       /* fp32 [T][320] or NULL                            */
+    const void* w1p;        /* packed, see above                                */
+    const float* b1;
+    const void* w2p;
+    const float* b2;
+    const void* r2;         /* fp16 [M][ldr2] or NULL                           */
+    void* out;              /* fp16 [M][ldo]                                    */
+    void* out_ln;           /* fp16 [M][ldoln] or NULL                          */
+    const float* ln_gamma;  /* fp32 [320] (with out_ln)                         */
+    const float* ln_beta;
+    int32_t M, ldx, ldo, ldr2, ldoln, HW, T;
+    float eps, s_acc, s1, s2, ln_eps;
+    int32_t reserved[4];    /* must be 0; sizeof(mofa_ff320_args) = 152         */
+} mofa_ff320_args;
+int mofa_ff320_f16(const mofa_ff320_args* a, mofa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Element-wise / data movement
  * ---------------------------------------------------------------------------------------- */
 /* y = a*x + b*y on contiguous fp32 vectors (latent window accumulation / averaging of the Keypoint loop,

@@ -20,7 +20,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .weights import (f32, interleave_geglu, pack_conv3d_t3, pack_conv3x3, pack_linear, pad_rows)
+from .weights import (f32, interleave_geglu, pack_conv3d_t3, pack_conv3x3, pack_ff320, pack_linear, pad_rows)
 
 BIG = 1 << 30
 
@@ -121,16 +121,34 @@ class LayerNorm:
 
 
 class GegluFF:
-    """diffusers FeedForward(dim, activation_fn='geglu'): net.0.proj (-> 8C), net.2 (4C -> dim_out)."""
+    """diffusers FeedForward(dim, activation_fn='geglu'): net.0.proj (-> 8C), net.2 (4C -> dim_out).
 
-    def __init__(self, s):
+    ``norm``: the Sub of the LayerNorm that always precedes this feed-forward (BasicTransformerBlock.norm3,
+    TemporalBasicTransformerBlock.norm_in / norm3).  At C = 320 (level 0) norm + projection + GELU gate + output projection +
+    residuals then run as ONE launch (``fused``, csrc/ff320.hip) whose packed operands carry the norm's gain / bias."""
+
+    def __init__(self, s, norm=None, norm_eps=1e-5):
         w, b = interleave_geglu(s.get("net.0.proj.weight"), s.get("net.0.proj.bias"))
         self.w1, self.b1 = s.dev(pack_linear(w)), s.dev(f32(b))
         self.out = Linear(s.sub("net.2"))
+        self.pk = None
+        if norm is not None and tuple(s.get("net.0.proj.weight").shape) == (2560, 320) and tuple(s.get("net.2.weight").shape) == (320, 1280):
+            w1p, b1f, w2p = pack_ff320(s.get("net.0.proj.weight"), s.get("net.0.proj.bias"), s.get("net.2.weight"),
+                                       norm.get("weight"), norm.get("bias"))
+            self.pk = (s.dev(w1p), s.dev(b1f), s.dev(w2p), norm_eps)
 
     def __call__(self, x, **epilogue):
         h = ops.igemm(x, self.w1, self.b1, act=L.ACT_GEGLU_PAIR)
         return self.out(h, **epilogue)
+
+    @property
+    def can_fuse(self):
+        return self.pk is not None and ops.FF_FUSED
+
+    def fused(self, x, **kw):
+        """x: the UN-normalised tokens; returns f16(f16(s_acc * ff(norm(x'))) + s1 * x' + s2 * r2) (ops.ff320)"""
+        w1p, b1f, w2p, eps = self.pk
+        return ops.ff320(x, w1p, b1f, w2p, self.out.b, eps=eps, **kw)
 
 
 def drive(gen):
@@ -356,11 +374,12 @@ class TransformerSpatioTemporal:
         self.proj_in, self.proj_out = Linear(s.sub("proj_in")), Linear(s.sub("proj_out"))
         b = s.sub("transformer_blocks.0")
         self.norm1, self.norm3 = LayerNorm(b.sub("norm1")), LayerNorm(b.sub("norm3"))
-        self.attn1, self.attn2, self.ff = SelfAttn(b.sub("attn1"), heads, fold_q_scale=True), CrossAttnVec(b.sub("attn2")), GegluFF(b.sub("ff"))
+        self.attn1, self.attn2, self.ff = (SelfAttn(b.sub("attn1"), heads, fold_q_scale=True), CrossAttnVec(b.sub("attn2")),
+                                           GegluFF(b.sub("ff"), norm=b.sub("norm3")))
         t = s.sub("temporal_transformer_blocks.0")
         self.norm_in, self.tnorm1, self.tnorm3 = LayerNorm(t.sub("norm_in")), LayerNorm(t.sub("norm1")), LayerNorm(t.sub("norm3"))
-        self.ff_in, self.tattn1, self.tattn2, self.tff = (GegluFF(t.sub("ff_in")), SelfAttn(t.sub("attn1"), heads),
-                                                          CrossAttnVec(t.sub("attn2")), GegluFF(t.sub("ff")))
+        self.ff_in, self.tattn1, self.tattn2, self.tff = (GegluFF(t.sub("ff_in"), norm=t.sub("norm_in")), SelfAttn(t.sub("attn1"), heads),
+                                                          CrossAttnVec(t.sub("attn2")), GegluFF(t.sub("ff"), norm=t.sub("norm3")))
         self.pos1, self.pos2 = Linear(s.sub("time_pos_embed.linear_1")), Linear(s.sub("time_pos_embed.linear_2"))
         self.alpha = _sigmoid(s.get("time_mixer.mix_factor").reshape(-1)[0])
         self.C = self.proj_in.w.shape[1]
@@ -385,12 +404,21 @@ class TransformerSpatioTemporal:
         q, k, v = self.attn1.qkv(self.norm1(h))
         a = ops.attn_spatial(q, k, v, N, self.heads, HW, head_dim=self.attn1.head_dim, prescaled=self.attn1.q_prescaled)
         h = self.attn1.to_out(a, r1=h, s1=1.0, rowvec=v_sp, rv=(T * HW, 1, 1, BIG))      # + attn1 + attn2
-        h = self.ff(self.norm3(h), r1=h, s1=1.0)                                          # x_spatial
+        # level 0 (C = 320): norm + feed-forward + residual(s) as one launch (GegluFF.fused); ff_in's launch also writes
+        # norm1(f), the input of the temporal attention's projections (the lane pair that owns a token holds its whole row)
+        h = self.ff.fused(h) if self.ff.can_fuse else self.ff(self.norm3(h), r1=h, s1=1.0)  # x_spatial
         # --- TemporalBasicTransformerBlock on h + pos[t] ---
         pos_rv = (HW, 1, 1, T)
-        f = self.ff_in(self.norm_in(h, rowvec=pos, rv_div=HW, rv_mod=T), r1=h, s1=1.0, rowvec=pos, rv=pos_rv)
+        fn = None
+        if self.ff_in.can_fuse:
+            f_own = None
+            if c.par is not None and c.par.kv_slots <= 32 and c.par.kv_inplace and c.par.gather_hidden:
+                hid, f_own = c.par.kv_buffer(HW, self.C, h.device)            # norm1(f) straight into this shard's gather slot
+            f, fn = self.ff_in.fused(h, pos=pos, HW=HW, T=T, ln_out=(self.tnorm1.g, self.tnorm1.b, f_own), ln_eps=self.tnorm1.eps)
+        else:
+            f = self.ff_in(self.norm_in(h, rowvec=pos, rv_div=HW, rv_mod=T), r1=h, s1=1.0, rowvec=pos, rv=pos_rv)
         if c.par is None:
-            q, k, v = self.tattn1.qkv(self.tnorm1(f))
+            q, k, v = self.tattn1.qkv(fn if fn is not None else self.tnorm1(f))
             a = ops.attn_temporal(q, k, v, B, T, HW, self.heads, head_dim=self.tattn1.head_dim)
         else:
             # this rank holds T of the clip's T_full frames.  The K|V projection writes this shard's slot of the gather
@@ -403,8 +431,9 @@ class TransformerSpatioTemporal:
                 # against ~1 ms of transfer saved).  LayerNorm writes this shard's slot of the gather buffer in place; the
                 # padding slots of shorter shards hold whatever the allocator left -- their K|V rows are computed but masked,
                 # never read by the attention kernel.
-                hid, own = par.kv_buffer(HW, Cc, f.device)
-                fn = self.tnorm1(f, out=own)
+                if fn is None:
+                    hid, own = par.kv_buffer(HW, Cc, f.device)
+                    fn = self.tnorm1(f, out=own)
                 work = par.kv_gather_begin(hid, HW)
                 q = self.tattn1.q(fn)
                 work.wait()
@@ -412,7 +441,7 @@ class TransformerSpatioTemporal:
                 a = ops.attn_temporal(q, kv[:, :Cc], kv[:, Cc:], 1, par.kv_slots, HW, self.heads,
                                       head_dim=self.tattn1.head_dim, Tq=T, key_mask=par.kv_mask)
             elif par.kv_slots <= 32 and par.kv_inplace:
-                fn = self.tnorm1(f)
+                fn = fn if fn is not None else self.tnorm1(f)
                 kv, own = par.kv_buffer(HW, 2 * Cc, fn.device)
                 self.tattn1.kv_into(fn, own)
                 work = par.kv_gather_begin(kv, HW)
@@ -422,7 +451,7 @@ class TransformerSpatioTemporal:
                                       head_dim=self.tattn1.head_dim, Tq=T, key_mask=par.kv_mask)
             else:   # more than 32 key slots after padding (e.g. 31 frames over 3 shards), or the in-place path failed
                     # its self-check on this transport (parallel.FrameParallel.self_check): compact to T_full frames
-                fn = self.tnorm1(f)
+                fn = fn if fn is not None else self.tnorm1(f)
                 q, k, v = self.tattn1.qkv(fn)
                 kv = torch.empty((q.shape[0], 2 * Cc), dtype=torch.float16, device=q.device)
                 ops.copy2d(k, kv[:, :Cc])
@@ -443,7 +472,10 @@ class TransformerSpatioTemporal:
             quirk = (T * HW, 0, HW, Bg)
         f = self.tattn1.to_out(a, r1=f, s1=1.0, rowvec=tab, rv=quirk)
         al = self.alpha
-        m = self.tff(self.tnorm3(f), s_acc=1.0 - al, r1=f, s1=1.0 - al, r2=h, s2=al)      # AlphaBlender
+        if self.tff.can_fuse:
+            m = self.tff.fused(f, s_acc=1.0 - al, s1=1.0 - al, r2=h, s2=al)                # AlphaBlender
+        else:
+            m = self.tff(self.tnorm3(f), s_acc=1.0 - al, r1=f, s1=1.0 - al, r2=h, s2=al)
         return self.proj_out(m, r1=x, s1=1.0, stats=out_stats, out=out)
 
 

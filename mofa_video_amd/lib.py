@@ -39,6 +39,17 @@ class IgemmArgs(C.Structure):
     ]
 
 
+class Ff320Args(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("pos", C.c_void_p), ("w1p", C.c_void_p), ("b1", C.c_void_p), ("w2p", C.c_void_p), ("b2", C.c_void_p),
+        ("r2", C.c_void_p), ("out", C.c_void_p), ("out_ln", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p),
+        ("M", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32), ("ldr2", C.c_int32), ("ldoln", C.c_int32),
+        ("HW", C.c_int32), ("T", C.c_int32),
+        ("eps", C.c_float), ("s_acc", C.c_float), ("s1", C.c_float), ("s2", C.c_float), ("ln_eps", C.c_float),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 # name -> argtypes (every symbol include/mofa_hip.h declares; tests check they all resolve)
@@ -46,6 +57,7 @@ PROTOTYPES = {
     "mofa_version": [],
     "mofa_igemm_f16": [_P, _P],                     # (const mofa_igemm_args*: a byref(IgemmArgs) or the packed 192 bytes)
     "mofa_igemm_stats_ok": [_P],
+    "mofa_ff320_f16": [_P, _P],                     # (const mofa_ff320_args*: the packed 152 bytes)
     "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_attn_spatial_qb_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],

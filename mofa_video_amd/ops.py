@@ -314,6 +314,51 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
     return out
 
 
+# ---- fused level-0 feed-forward -------------------------------------------------------------------------
+_FF320_ARGS = struct.Struct("@11P7i5f4i")
+assert _FF320_ARGS.size == C.sizeof(L.Ff320Args)
+FF_FUSED = True          # A/B switch: False = LayerNorm + two implicit GEMMs for every feed-forward (blocks.GegluFF)
+
+
+def ff320(x, w1p, b1, w2p, b2, eps=1e-5, pos=None, HW=1, T=1, r2=None, s_acc=1.0, s1=1.0, s2=0.0, out=None,
+          ln_out=None, ln_eps=1e-5):
+    """out = f16(f16(s_acc * FF(LayerNorm(x'))) + s1 * x' + s2 * r2), x' = x + pos[(m / HW) % T]; FF = GEGLU feed-forward
+    320 -> 1280 -> 320 with the norm's affine part folded into the packed projection (weights.pack_ff320).  ln_out = (gamma,
+    beta[, buffer]): also returns LayerNorm(out) * gamma + beta (the norm in front of the next projection).  See
+    mofa_ff320_f16 in include/mofa_hip.h."""
+    lib = L.load()
+    _chk(x, F16)
+    M = x.shape[0]
+    assert x.shape[1] == 320 and w1p.dtype is F16 and w2p.dtype is F16 and w1p.numel() == 2560 * 320 and w2p.numel() == 320 * 1280
+    assert b1.dtype is F32 and b1.numel() == 2560 and b2.dtype is F32 and b2.numel() == 320
+    if out is None:
+        out = torch.empty((M, 320), dtype=F16, device=x.device)
+    else:
+        assert out.dtype is F16 and out.shape[0] == M and out.shape[1] >= 320
+        _written(out)
+    if pos is not None:
+        assert pos.dtype is F32 and pos.is_contiguous() and pos.shape == (T, 320)
+    if r2 is not None:
+        assert r2.dtype is F16 and r2.shape[0] == M and r2.shape[1] >= 320
+    yl = pg = pb = None
+    if ln_out is not None:
+        pg, pb = ln_out[0], ln_out[1]
+        yl = ln_out[2] if len(ln_out) > 2 and ln_out[2] is not None else torch.empty((M, 320), dtype=F16, device=x.device)
+        assert yl.dtype is F16 and yl.shape[0] == M and pg.dtype is F32 and pb.dtype is F32
+        _written(yl)
+    args = _FF320_ARGS.pack(x.data_ptr(), L.ptr(pos) or 0, w1p.data_ptr(), b1.data_ptr(), w2p.data_ptr(), b2.data_ptr(),
+                            L.ptr(r2) or 0, out.data_ptr(), L.ptr(yl) or 0, L.ptr(pg) or 0, L.ptr(pb) or 0,
+                            M, _ld(x), _ld(out), _ld(r2) if r2 is not None else 0, _ld(yl) if yl is not None else 0, HW, T,
+                            eps, s_acc, s1, s2 if r2 is not None else 0.0, ln_eps, 0, 0, 0, 0)
+    t0 = TIMER.start() if TIMER is not None else None
+    rc = lib.mofa_ff320_f16(args, L.stream_ptr())
+    if rc != 0:
+        L.check(rc, "mofa_ff320_f16")
+    if t0 is not None:                                        # counted with the implicit GEMMs it replaces (roofline leg of bench.py)
+        TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * (2560 * 320 + 320 * 1280), tag=(9, 0, 0, M, 320, 320, 0))
+    return out if ln_out is None else (out, yl)
+
+
 # ---- attention -----------------------------------------------------------------------------------------
 Q_FOLD_LOG2E = 1.4426950408889634
 

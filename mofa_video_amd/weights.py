@@ -58,5 +58,33 @@ def interleave_geglu(w, b):
     return w[idx].contiguous(), (b[idx].contiguous() if b is not None else None)
 
 
+def pack_ff320(w1, b1, w2, gamma, beta):
+    """Operands of the fused level-0 feed-forward (csrc/ff320.hip, ``mofa_ff320_f16``; layout in include/mofa_hip.h) from the
+    diffusers parameters of FeedForward(320, activation_fn="geglu") and the LayerNorm in front of it:
+    ``w1`` = net.0.proj.weight [2560, 320] (rows [0, 1280) value, [1280, 2560) gate), ``b1`` = net.0.proj.bias, ``w2`` =
+    net.2.weight [320, 1280], ``gamma`` / ``beta`` = the norm's weight / bias.  The norm's affine part is folded in fp32:
+    W1 . (g * xhat + b) + b1 = (W1 * g) . xhat + (W1 . b + b1); weights are rounded to fp16 once, afterwards.
+    Returns (w1p fp16 [40, 2, 20, 64, 8], b1 fp32 [2560], w2p fp16 [40, 10, 2, 64, 8])."""
+    C, H = 320, 1280
+    w1, w2 = w1.detach().float().reshape(2 * H, C), w2.detach().float().reshape(C, H)
+    gamma, beta = gamma.detach().float(), beta.detach().float()
+    b1f = (b1.detach().float() if b1 is not None else torch.zeros(2 * H)) + w1 @ beta
+    w1g = (w1 * gamma[None, :]).to(torch.float16)
+    lane = torch.arange(64)
+    n, lh = lane % 32, lane // 32
+    # w1p[c, t, s, l, e] = w1g[t * 1280 + 32 c + n(l), 16 s + 8 lh(l) + e]
+    c, t, s_, e = torch.arange(40), torch.arange(2), torch.arange(20), torch.arange(8)
+    rows = (t[None, :, None, None, None] * H + 32 * c[:, None, None, None, None] + n[None, None, None, :, None])
+    cols = 16 * s_[None, None, :, None, None] + 8 * lh[None, None, None, :, None] + e[None, None, None, None, :]
+    w1p = w1g[rows.expand(40, 2, 20, 64, 8), cols.expand(40, 2, 20, 64, 8)].contiguous()
+    # w2p[c, j, u, l, jj] = w2[32 j + n(l), 32 c + 16 u + 4 lh(l) + (jj & 3) + 8 (jj >> 2)]
+    j, u, jj = torch.arange(10), torch.arange(2), torch.arange(8)
+    rows2 = 32 * j[None, :, None, None, None] + n[None, None, None, :, None]
+    cols2 = (32 * c[:, None, None, None, None] + 16 * u[None, None, :, None, None] + 4 * lh[None, None, None, :, None] +
+             (jj & 3)[None, None, None, None, :] + 8 * (jj >> 2)[None, None, None, None, :])
+    w2p = w2.to(torch.float16)[rows2.expand(40, 10, 2, 64, 8), cols2.expand(40, 10, 2, 64, 8)].contiguous()
+    return w1p, b1f.contiguous(), w2p
+
+
 def f32(t):
     return t.detach().to(torch.float32).contiguous()

@@ -93,6 +93,54 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
     return y
 
 
+def unpack_ff320(w1p, w2p):
+    """inverse of weights.pack_ff320, written from the layout include/mofa_hip.h documents for mofa_ff320_f16 (not from the
+    packer): -> (W1g fp16 [2560, 320], W2 fp16 [320, 1280])"""
+    w1p, w2p = w1p.reshape(40, 2, 20, 64, 8).cpu(), w2p.reshape(40, 10, 2, 64, 8).cpu()
+    w1 = torch.zeros(2560, 320, dtype=F16)
+    w2 = torch.zeros(320, 1280, dtype=F16)
+    for l in range(64):
+        n, lh = l & 31, l >> 5
+        for t in range(2):
+            # element e of lane l, chunk c, k-step s = W1g[t * 1280 + 32 c + n][16 s + 8 lh + e]
+            blk = w1p[:, t, :, l, :]                                     # [40 c, 20 s, 8 e]
+            rows = t * 1280 + 32 * torch.arange(40) + n
+            cols = (16 * torch.arange(20)[:, None] + 8 * lh + torch.arange(8)[None, :]).reshape(-1)
+            w1[rows[:, None], cols[None, :]] = blk.reshape(40, 160)
+        for jj in range(8):
+            # element jj of lane l, chunk c, out tile j, k-step u = W2[32 j + n][32 c + 16 u + 4 lh + (jj & 3) + 8 (jj >> 2)]
+            blk = w2p[:, :, :, l, jj]                                    # [40 c, 10 j, 2 u]
+            rows = 32 * torch.arange(10) + n
+            cols = 32 * torch.arange(40)[:, None] + 16 * torch.arange(2)[None, :] + 4 * lh + (jj & 3) + 8 * (jj >> 2)
+            w2[rows[None, :, None], cols[:, None, :]] = blk
+    return w1, w2
+
+
+def ff320(x, w1p, b1, w2p, b2, eps=1e-5, pos=None, HW=1, T=1, r2=None, s_acc=1.0, s1=1.0, s2=0.0, out=None, ln_out=None,
+          ln_eps=1e-5):
+    w1, w2 = unpack_ff320(w1p, w2p)
+    xf = x[:, :320].float()
+    if pos is not None:
+        xf = xf + pos.float()[(torch.arange(x.shape[0]) // HW) % T]
+    xn = F.layer_norm(xf, (320,), None, None, eps).to(F16).float()
+    p = xn @ w1.float().T + b1.float()
+    h = (p[:, :1280] * F.gelu(p[:, 1280:])).to(F16).float()
+    y = (s_acc * (h @ w2.float().T + b2.float())).to(F16).float() + s1 * xf
+    if r2 is not None:
+        y = y + s2 * r2[:, :320].float()
+    y = y.to(F16)
+    if out is not None:
+        out[:, :320].copy_(y)
+        y = out
+    if ln_out is None:
+        return y
+    yl = F.layer_norm(y[:, :320].float(), (320,), ln_out[0], ln_out[1], ln_eps).to(F16)
+    if len(ln_out) > 2 and ln_out[2] is not None:
+        ln_out[2][:, :320].copy_(yl)
+        yl = ln_out[2]
+    return y, yl
+
+
 def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None):
     C = gamma.numel()
     fps = frames_per_stat
@@ -257,7 +305,7 @@ def resize_nearest_f32(x, h, w):
     return torch.nn.functional.interpolate(x[None].float(), size=(h, w), mode="nearest")[0]
 
 
-NAMES = ["attn_temporal", "timestep_embedding", "silu_f32", "axpby_", "axpby_out", "copy2d", "gn_nparts", "gn_partial_into", "gn_apply_gathered", "resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
+NAMES = ["attn_temporal", "timestep_embedding", "silu_f32", "axpby_", "axpby_out", "copy2d", "gn_nparts", "gn_partial_into", "gn_apply_gathered", "resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "ff320", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
          "tokens_to_nchw", "patchify", "filter1d_reflect", "resize_bicubic_ac"]
 
 

@@ -319,14 +319,16 @@ def test_grouped_layout_and_window_cost_table():
 # the WHOLE UNet forward of a rank of the 2-way CFG x frame-shard layout over gloo against the unsharded forward
 # (host graph + exchange protocol end to end; the HIP entry points are the torch stand-ins of tests/emu_ops.py)
 # ---------------------------------------------------------------------------------------------------------
-def _unet_worker(rank, world, port, T):
+def _unet_worker(rank, world, port, T, cfg_name="TINY"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         import emu_ops
-        from helpers import TINY, rel_l2
+        import helpers
+        from helpers import rel_l2
+        TINY = getattr(helpers, cfg_name)      # LDMK_UNET: 320 channels at level 0 -> the fused feed-forward path (ops.ff320)
         emu_ops.install()
         from mofa_video_amd import ops, schema
         from mofa_video_amd.parallel import FrameParallel, Layout, TorchComm
@@ -372,3 +374,9 @@ def test_sharded_unet_forward_gloo(world, T):
     flips last fp16 bits that then propagate; on the GPU the same comparison is bit-identical at world 2 and 8e-4 at 4 / 8
     (tests/test_sharded_gpu.py), because a tile's arithmetic does not depend on how many tiles the launch has."""
     mp.spawn(_unet_worker, args=(world, _free_port(), T), nprocs=world, join=True)
+
+
+def test_sharded_unet_forward_fused_ff_gloo():
+    """the same with 320 channels at level 0: the level-0 feed-forwards take the fused launch (blocks.GegluFF.fused), whose second
+    output -- norm1 of the temporal block -- is written straight into the rank's slot of the hidden-token all-gather buffer"""
+    mp.spawn(_unet_worker, args=(4, _free_port(), 5, "LDMK_UNET"), nprocs=4, join=True)
