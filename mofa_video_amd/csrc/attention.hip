@@ -198,12 +198,19 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     }
     __syncthreads();
 
+#if defined(ATT_T_NOREADK) || defined(ATT_T_NOREADV)
+    f16x8 kstale[KK];                                               // fragments read ONCE (tile 0), reused for every tile
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) kstale[kk] = *(const f16x8*)(sKb + l31 * ATT_KSTR + kk * 16 + lh * 8);
+#endif
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int k0 = t * ATT_TILE;
         if (t + 1 < ntiles) {
+#ifndef ATT_T_NODMA
             if constexpr (DMA) dma_tile(t + 1, buf ^ 1);            // (the other buffer was released by the last barrier)
             else load_tile(k0 + ATT_TILE);
+#endif
         }
 
         // ---- S^T tiles: s[b][ts][r] = score(key = k0 + 32*ts + (r&3) + 8*(r>>2) + 4*lh, query = 32*b + l31) ----
@@ -222,7 +229,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             const f16* kp = sKb + buf * ATT_TILE * ATT_KSTR + (ts * 32 + l31) * ATT_KSTR + (DMA ? 0 : lh * 8);
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
+#ifdef ATT_T_NOREADK                           // timing-only builds (wrong results; the data flow stays): tools/attn_anatomy.sh
+                const f16x8 kf = kstale[kk];
+#else
                 const f16x8 kf = *(const f16x8*)(kp + (DMA ? ((2 * kk + lh) ^ ksw) * 8 : kk * 16));
+#endif
 #pragma unroll
                 for (int b = 0; b < QB; ++b)
                     s[b][ts] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[b][kk], (NEGM && kk == 0) ? negm[b] : s[b][ts], 0, 0, 0);
@@ -258,8 +269,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
+#ifdef ATT_T_NOEXP
+                    const float p = s[b][ts][r] * 1e-3f;                  // (one full-rate multiply instead of the quarter-rate v_exp_f32)
+#else
                     const float p = __builtin_amdgcn_exp2f(s[b][ts][r]);   // raw v_exp_f32
+#endif
+#ifndef ATT_T_NOSUM
                     psum += p;
+#endif
                     pf[b][ts][r >> 3][r & 7] = (f16)p;
                 }
             const float ptot = psum + __shfl_xor(psum, 32, 64);           // both key halves of the query row
@@ -306,9 +323,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             for (int ts = 0; ts < 2; ++ts)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
+#ifdef ATT_T_NOREADV
+                    const f16x8 vf = kstale[(db + ts + u) % KK];
+#else
                     const f16x4 lo = lds_read_tr4(vp + (ts * 32 + u * 16) * ATT_VSTR);        // keys k0 + 4 lh + 0..3
                     const f16x4 hi = lds_read_tr4(vp + (ts * 32 + u * 16 + 8) * ATT_VSTR);    // keys k0 + 4 lh + 8..11
                     const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#endif
 #pragma unroll
                     for (int b = 0; b < QB; ++b) o[b][db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[b][ts][u], o[b][db], 0, 0, 0);
                 }
@@ -317,7 +338,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t + 1 have landed
             else store_tile(buf ^ 1);
         }
+#ifndef ATT_T_NOBAR
         __syncthreads();
+#endif
     }
 
 #pragma unroll

@@ -78,18 +78,11 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
     const unsigned voff = (unsigned)lane * 16u;
     // a wave fetches blocks wave, wave + 4, ... of a chunk image: 10 of W1's 40, 5 of W2's 20 (1 KB each)
     auto dma_w1 = [&](int chunk, int slot) __attribute__((always_inline)) {
-        char* dst = smem_ff + OFF_W1 + slot * W1_SLOT + wave * 1024;
-        const int src = chunk * W1_SLOT + wave * 1024;
+        char* dst = smem_ff + OFF_W1 + slot * W1_SLOT + wave * 10240;
+        const int src = chunk * W1_SLOT + wave * 10240;
 #pragma unroll
         for (int i = 0; i < 10; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, FF_LDS_PTR(dst + i * 4096), 16, voff, src + i * 4096, 0, 0);
-    };
-    auto dma_w2 = [&](int chunk, int slot) __attribute__((always_inline)) {
-        char* dst = smem_ff + OFF_W2 + slot * W2_SLOT + wave * 1024;
-        const int src = chunk * W2_SLOT + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 5; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, FF_LDS_PTR(dst + i * 4096), 16, voff, src + i * 4096, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, FF_LDS_PTR(dst + i * 1024), 16, voff, src + i * 1024, 0, 0);
     };
 
     const char* wl = smem_ff + lane * 16;                          // this lane's 16 bytes of every 1 KB block
@@ -131,9 +124,12 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
         static_assert(NS >= 20, "every step has MFMA slots");
         const char* w1 = wl + OFF_W1 + slot_a * W1_SLOT;
         const char* w2 = wl + OFF_W2 + P * W2_SLOT;
-        char* dst1 = smem_ff + OFF_W1 + slot_w1 * W1_SLOT + wave * 1024;
-        char* dst2 = smem_ff + OFF_W2 + (P ^ 1) * W2_SLOT + wave * 1024;
-        const int src1 = chunk_w1 * W1_SLOT + wave * 1024, src2 = chunk_w2 * W2_SLOT + wave * 1024;
+        // this wave's pieces: a CONTIGUOUS run of blocks (W1: 10 wave .. + 9, W2: 5 wave .. + 4), four pieces per LDS base / scalar
+        // offset, the piece inside a group picked by the instruction's immediate offset (it advances both addresses:
+        // tools/lds_dma_range.hip) -- a third of the s_mov m0 / s_add per piece that one base per piece costs
+        char* dst1 = smem_ff + OFF_W1 + slot_w1 * W1_SLOT + wave * 10240;
+        char* dst2 = smem_ff + OFF_W2 + (P ^ 1) * W2_SLOT + wave * 5120;
+        const int src1 = chunk_w1 * W1_SLOT + wave * 10240, src2 = chunk_w2 * W2_SLOT + wave * 5120;
         if constexpr (A) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -150,7 +146,8 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
             const int t = i - NC;
             return *(const f16x8*)(w1 + ((t & 1) * FF_KS + (t >> 1)) * 1024);
         };
-        f16x8 ring[FF_LOOK];
+        constexpr int FF_RING = FF_LOOK + 2;                       // fragment j sits in ring[j % FF_RING]
+        f16x8 ring[FF_RING];
 #pragma unroll
         for (int i = 0; i < FF_LOOK; ++i) ring[i] = frag(i);
         // GELU micro-operations of pair d (hidden registers 2 d, 2 d + 1 of p[P ^ 1]): x * Phi(x), Phi as in gelu_phi_f (common.h);
@@ -203,15 +200,22 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
         auto dma_piece = [&](auto pcc) __attribute__((always_inline)) {
             constexpr int pc = decltype(pcc)::v, n2 = D2 ? 5 : 0;
             if constexpr (pc < n2)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, FF_LDS_PTR(dst2 + pc * 4096), 16, voff, src2 + pc * 4096, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, FF_LDS_PTR(dst2 + (pc >> 2) * 4096), 16, voff, src2 + (pc >> 2) * 4096,
+                                                         (pc & 3) * 1024, 0);
             else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, FF_LDS_PTR(dst1 + (pc - n2) * 4096), 16, voff, src1 + (pc - n2) * 4096, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, FF_LDS_PTR(dst1 + ((pc - n2) >> 2) * 4096), 16, voff,
+                                                         src1 + ((pc - n2) >> 2) * 4096, ((pc - n2) & 3) * 1024, 0);
         };
         static_for<0, NS>([&](auto ic) __attribute__((always_inline)) {
             constexpr int i = decltype(ic)::v;
-            const f16x8 af = ring[i % FF_LOOK];
+            const f16x8 af = ring[i % FF_RING];
 #ifndef FF_T_NOREAD
-            if constexpr (i + FF_LOOK < NS) ring[i % FF_LOOK] = frag(i + FF_LOOK);
+            // reads are issued two at a time on even slots, the LATER fragment first: LDS returns in order, so the s_waitcnt in
+            // front of the MFMA that needs the earlier (younger) one covers the next MFMA's too -- one wait per two MFMAs
+            if constexpr ((i & 1) == 0) {
+                if constexpr (i + FF_LOOK + 1 < NS) ring[(i + FF_LOOK + 1) % FF_RING] = frag(i + FF_LOOK + 1);
+                if constexpr (i + FF_LOOK < NS) ring[(i + FF_LOOK) % FF_RING] = frag(i + FF_LOOK);
+            }
 #endif
             if constexpr ((i & 1) == 0 && (i >> 1) < NPIECE) dma_piece(IC<(i >> 1)>{});   // one piece every other slot, from slot 0
             if constexpr (i < NC) {

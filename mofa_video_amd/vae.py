@@ -22,8 +22,9 @@ def _res(s):
 class _MidAttention:
     """diffusers Attention(heads=1, dim_head=512, group norm 32 eps 1e-6, bias, residual_connection)."""
 
-    def __init__(self, s):
-        self.norm = GroupNorm(s.sub("group_norm"), 1e-6)
+    def __init__(self, s, scale=1.0):
+        self.s = scale                                             # input / output stored as scale * value (Encoder); 1 in the decoder
+        self.norm = GroupNorm(s.sub("group_norm"), 1e-6 * scale * scale)
         self.to_q, self.to_k, self.to_v = Linear(s.sub("to_q")), Linear(s.sub("to_k")), Linear(s.sub("to_v"))
         self.to_out = Linear(s.sub("to_out.0"))
         self.C = self.to_q.w.shape[0]
@@ -41,44 +42,63 @@ class _MidAttention:
             p = ops.igemm(q[rows], k[rows].contiguous(), s_acc=scale)    # [S, S] = Q K^T / sqrt(d)
             ops.softmax_rows_(p)
             ops.igemm(p, vt[f * Cc:(f + 1) * Cc], out=o[rows])           # P V
-        return self.to_out(o, r1=x, s1=1.0)
+        return self.to_out(o, r1=x, s1=1.0, s_acc=self.s)
+
+
+ENC_SCALE = 2.0 ** -5      # the encoder's residual stream and convolution outputs are stored as ENC_SCALE * value (see Encoder)
 
 
 class _ResnetBlock2D:
-    """diffusers ResnetBlock2D without time embedding (VAE encoder): GN-SiLU-conv, GN-SiLU-conv (+ 1x1 shortcut)."""
+    """diffusers ResnetBlock2D without time embedding (VAE encoder): GN-SiLU-conv, GN-SiLU-conv (+ 1x1 shortcut).
+    ``s``: the block's input, the output of conv1 and the block's output are stored as s * value (Encoder)."""
 
-    def __init__(self, s, eps=1e-6):
-        self.norm1, self.norm2 = GroupNorm(s.sub("norm1"), eps), GroupNorm(s.sub("norm2"), eps)
+    def __init__(self, s, eps=1e-6, scale=1.0):
+        self.s = scale
+        self.norm1, self.norm2 = GroupNorm(s.sub("norm1"), eps * scale * scale), GroupNorm(s.sub("norm2"), eps * scale * scale)
         self.conv1, self.conv2 = Conv3x3(s.sub("conv1")), Conv3x3(s.sub("conv2"))
         self.shortcut = Linear(s.sub("conv_shortcut")) if s.has("conv_shortcut.weight") else None
+        if self.shortcut is not None and self.shortcut.b is not None:
+            self.shortcut.b = self.shortcut.b * scale              # its input is already scaled: W (s x) + s b = s (W x + b)
 
     def __call__(self, x, n, H, W):
-        h = self.conv1(self.norm1(x, n, H * W, silu=True), H, W)
+        h = self.conv1(self.norm1(x, n, H * W, silu=True), H, W, s_acc=self.s)
         h = self.norm2(h, n, H * W, silu=True)
         xs = self.shortcut(x) if self.shortcut is not None else x
-        return self.conv2(h, H, W, r1=xs, s1=1.0)
+        return self.conv2(h, H, W, r1=xs, s1=1.0, s_acc=self.s)
 
 
 class Encoder:
     """diffusers models/vae.py Encoder (DownEncoderBlock2D x N, UNetMidBlock2D, GN-SiLU-conv_out) with ``quant_conv``
     folded into ``conv_out`` (both linear, nothing between them) and only the mean rows kept: the reference reads
-    ``latent_dist.mode()`` = the first ``latent_channels`` of the moments (pipeline.py:150)."""
+    ``latent_dist.mode()`` = the first ``latent_channels`` of the moments (pipeline.py:150).
 
-    def __init__(self, s, quant, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4):
+    RANGE.  The reference upcasts the VAE to fp32 for this call (``force_upcast``, pipeline.py:343-352) because trained VAE
+    activations leave the fp16 range.  Here every tensor BETWEEN GroupNorms -- the residual stream and each convolution's output --
+    is stored as ``scale`` x its value, scale = 2^-5: GroupNorm is invariant under a common factor once its eps is scaled with it
+    (GN_{eps s^2}(s x) = GN_eps(x)), convolutions are linear (``s_acc = s`` where the input is a norm's output; the bias times s
+    where the input is the scaled stream), and a power of two is exact in floating point.  So fp16 storage holds values up to
+    2.1e6 (the stream of a trained SVD VAE stays far below) with unchanged relative precision down to 2e-3 in absolute value;
+    accumulation, norm statistics and softmax are fp32 as everywhere.  tests/test_frontend_gpu.py drives an encoder whose stream
+    reaches ~3e5 -- inf / NaN without the factor -- against the fp32 oracle."""
+
+    def __init__(self, s, quant, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4, scale=None):
+        sc = self.scale = ENC_SCALE if scale is None else float(scale)
         self.conv_in = Conv3x3(s.sub("conv_in"))
         self.in_ld = self.conv_in.w.shape[1] // 9
         self.down = []
         n = len(block_out_channels)
         for i in range(n):
             b = s.sub(f"down_blocks.{i}")
-            res = [_ResnetBlock2D(b.sub(f"resnets.{j}")) for j in range(layers_per_block)]
+            res = [_ResnetBlock2D(b.sub(f"resnets.{j}"), scale=sc) for j in range(layers_per_block)]
             # Downsample2D(padding=0): F.pad(x, (0, 1, 0, 1)) then a stride-2 conv = trailing-only padding
             down = Conv3x3(b.sub("downsamplers.0.conv"), stride=2, pad=L.PAD_TRAILING) if i != n - 1 else None
+            if down is not None:
+                down.b = down.b * sc                                 # (scaled stream in, scaled stream out)
             self.down.append((res, down))
         m = s.sub("mid_block")
-        self.mid_res = [_ResnetBlock2D(m.sub(f"resnets.{j}")) for j in range(2)]
-        self.mid_attn = _MidAttention(m.sub("attentions.0"))
-        self.conv_norm_out = GroupNorm(s.sub("conv_norm_out"), 1e-6)
+        self.mid_res = [_ResnetBlock2D(m.sub(f"resnets.{j}"), scale=sc) for j in range(2)]
+        self.mid_attn = _MidAttention(m.sub("attentions.0"), scale=sc)
+        self.conv_norm_out = GroupNorm(s.sub("conv_norm_out"), 1e-6 * sc * sc)
         wc, bc = s.get("conv_out.weight").float(), s.get("conv_out.bias").float()            # [2z, C, 3, 3]
         wq, bq = quant.get("weight").float().flatten(1), quant.get("bias").float()            # [2z, 2z]
         w = torch.einsum("om,mcyx->ocyx", wq, wc)[:latent_channels]
@@ -87,7 +107,7 @@ class Encoder:
         self.latent_channels = latent_channels
 
     def __call__(self, x, n, H, W):
-        x = self.conv_in(x, H, W)
+        x = self.conv_in(x, H, W, s_acc=self.scale)
         for res, down in self.down:
             for r in res:
                 x = r(x, n, H, W)
@@ -98,7 +118,7 @@ class Encoder:
         x = self.mid_attn(x, n, H * W)
         x = self.mid_res[1](x, n, H, W)
         x = self.conv_norm_out(x, n, H * W, silu=True)
-        return ops.igemm(x, self.out_w, self.out_b, geom=ops.conv3x3_geom(H, W)), H, W      # [n*H*W, z] mean
+        return ops.igemm(x, self.out_w, self.out_b, geom=ops.conv3x3_geom(H, W)), H, W      # [n*H*W, z] mean (unscaled)
 
 
 class _Posterior:
@@ -167,11 +187,12 @@ class AutoencoderKLTemporalDecoder:
         self.encoder = None
         if "encoder.conv_in.weight" in state_dict:
             self.encoder = Encoder(Sub(state_dict, "encoder.", device), Sub(state_dict, "quant_conv.", device),
-                                   tuple(cfg["block_out_channels"]), cfg["layers_per_block"], cfg["latent_channels"])
+                                   tuple(cfg["block_out_channels"]), cfg["layers_per_block"], cfg["latent_channels"],
+                                   scale=cfg.get("encoder_range_scale"))
 
     def encode(self, x):
         """x fp32 [n, 3, H, W] in [-1, 1] -> ``.latent_dist.mode()`` fp32 [n, 4, H/8, W/8] (the reference upcasts the
-        VAE to fp32 for this call, pipeline.py:343-352; here fp16 storage with fp32 accumulation)"""
+        VAE to fp32 for this call, pipeline.py:343-352, for range; here fp16 storage of 2^-5-scaled tensors: ``Encoder``)"""
         if self.encoder is None:
             raise ValueError("this AutoencoderKLTemporalDecoder was built from a state_dict without encoder.* weights")
         n, c, H, W = x.shape

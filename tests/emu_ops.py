@@ -93,7 +93,17 @@ def layer_norm(x, gamma, beta, eps=1e-5, rowvec=None, rv_div=1, rv_mod=1, out=No
     return y
 
 
+_UNPACKED = {}
+
+
 def unpack_ff320(w1p, w2p):
+    key = (w1p.data_ptr(), w2p.data_ptr())
+    if key not in _UNPACKED:
+        _UNPACKED[key] = (_unpack_ff320(w1p, w2p), w1p, w2p)       # (the packed tensors are kept alive with the entry)
+    return _UNPACKED[key][0]
+
+
+def _unpack_ff320(w1p, w2p):
     """inverse of weights.pack_ff320, written from the layout include/mofa_hip.h documents for mofa_ff320_f16 (not from the
     packer): -> (W1g fp16 [2560, 320], W2 fp16 [320, 1280])"""
     w1p, w2p = w1p.reshape(40, 2, 20, 64, 8).cpu(), w2p.reshape(40, 10, 2, 64, 8).cpu()

@@ -379,4 +379,4 @@ def test_sharded_unet_forward_gloo(world, T):
 def test_sharded_unet_forward_fused_ff_gloo():
     """the same with 320 channels at level 0: the level-0 feed-forwards take the fused launch (blocks.GegluFF.fused), whose second
     output -- norm1 of the temporal block -- is written straight into the rank's slot of the hidden-token all-gather buffer"""
-    mp.spawn(_unet_worker, args=(4, _free_port(), 5, "LDMK_UNET"), nprocs=4, join=True)
+    mp.spawn(_unet_worker, args=(4, _free_port(), 4, "LDMK_UNET"), nprocs=4, join=True)

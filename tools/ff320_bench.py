@@ -56,6 +56,8 @@ def main():
             ("spatial ff", lambda: ff.fused(x), lambda: ff(norm(x), r1=x, s1=1.0)),
             ("ff_in (+pos, +norm1 out)", lambda: ff.fused(x, pos=pos, HW=HW, T=T, ln_out=(lng, lnb)),
              lambda: norm(ff(norm(x, rowvec=pos, rv_div=HW, rv_mod=T), r1=x, s1=1.0, rowvec=pos, rv=(HW, 1, 1, T)))),
+            ("ff_in (+pos), norm1 stand-alone", lambda: norm(ff.fused(x, pos=pos, HW=HW, T=T)),
+             lambda: norm(ff(norm(x, rowvec=pos, rv_div=HW, rv_mod=T), r1=x, s1=1.0, rowvec=pos, rv=(HW, 1, 1, T)))),
             ("temporal ff (AlphaBlender)", lambda: ff.fused(x, s_acc=0.7, s1=0.7, r2=h, s2=0.3),
              lambda: ff(norm(x), s_acc=0.7, r1=x, s1=0.7, r2=h, s2=0.3)),
         ]

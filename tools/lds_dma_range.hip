@@ -1,4 +1,4 @@
-// Probe: does LDS-DMA (buffer_load ... lds) reach every 1 KB block of a 160 KB dynamic LDS allocation?  One workgroup DMAs block b of
+// Probe (round 6): the instruction's immediate offset of an LDS-DMA advances the global AND the LDS address; and does LDS-DMA (buffer_load ... lds) reach every 1 KB block of a 160 KB dynamic LDS allocation?  One workgroup DMAs block b of
 // a global pattern to LDS block b for b = 0 .. 159 and reads the LDS back with ds_read.   hipcc --offload-arch=gfx950 -O2 -o /tmp/p tools/lds_dma_range.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -10,8 +10,14 @@ __global__ __launch_bounds__(256, 1) void probe(const unsigned* src, unsigned* o
     for (int i = threadIdx.x; i < nblk * 256; i += 256) ((unsigned*)smem)[i] = 0xdeadbeefu;
     __syncthreads();
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)nblk * 1024u, 0x00020000);
-    for (int b = wave; b < nblk; b += 4)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + b * 1024), 16, lane * 16, b * 1024, 0, 0);
+    // groups of 4 blocks: ONE LDS base / scalar offset, the block inside the group selected by the instruction's immediate offset --
+    // it must advance BOTH the global and the LDS address
+    for (int g = wave; g < nblk / 4; g += 4) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + g * 4096), 16, lane * 16, g * 4096, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + g * 4096), 16, lane * 16, g * 4096, 1024, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + g * 4096), 16, lane * 16, g * 4096, 2048, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + g * 4096), 16, lane * 16, g * 4096, 3072, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int i = threadIdx.x; i < nblk * 256; i += 256) out[i] = ((unsigned*)smem)[i];
