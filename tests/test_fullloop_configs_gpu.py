@@ -37,7 +37,7 @@ T, H, W = bench.T, bench.H, bench.W
 STEPS = int(os.environ.get("MOFA_FULLLOOP_STEPS", "25"))
 LONG_FRAMES = int(os.environ.get("MOFA_FULLLOOP_LONG_FRAMES", "49"))
 LONG_STEPS = int(os.environ.get("MOFA_FULLLOOP_LONG_STEPS", "8"))
-W8_STEPS = min(10, STEPS)
+W8_STEPS = min(int(os.environ.get("MOFA_FULLLOOP_W8_STEPS", "10")), STEPS)   # opt-in: 25 (profiles/r06_fullloop_full_steps.log)
 TOL = 2e-2
 
 
