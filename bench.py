@@ -353,7 +353,9 @@ def cpu_baseline(timeout=420):
                         f"(FlopCounterMode) in {d['dt']:.1f} s = {r_unet:.4f} TFLOP/s; (2) the temporal VAE decoder on a 2-frame chunk "
                         f"at the full 576x1024 = {d['tflop_vae']:.3f} TFLOP in {d['dt_vae']:.1f} s = {r_vae:.4f} TFLOP/s (model set-up "
                         f"{d['setup']:.0f} s untimed); value = 25 frames / (25 x 218.58 TFLOP / rate 1 + 173.57 TFLOP / rate 2) = "
-                        f"25 / {clip_s:.0f} s"))
+                        f"25 / {clip_s:.0f} s.  The full-size figure exists too: ONE denoise step of this oracle at 25 f 576x1024 = 294 s "
+                        f"on 64 threads (0.744 TFLOP/s) => 0.0033 frames/s, profiles/r04b_cpu_baseline_full.json (python bench.py "
+                        f"--cpu-baseline-full, several minutes)"))
 
 
 def spawn_command(n, argv, port):
@@ -410,6 +412,8 @@ def main():
     ap.add_argument("--split-decoder", type=int, default=-1, help="A/B switch: pipeline.split_decoder = 0 | 1 (default: the pipeline's)")
     ap.add_argument("--gn-stats", type=int, default=-1, help="A/B switch: ops.GN_STATS = 0 | 1 (GroupNorm partial sums from the "
                     "producing implicit-GEMM epilogue; default: on)")
+    ap.add_argument("--ff-fused", type=int, default=-1, help="A/B switch: ops.FF_FUSED = 0 | 1 (the level-0 feed-forwards as one fused launch "
+                    "each, or LayerNorm + two implicit GEMMs; default: on)")
     ap.add_argument("--lib", default="", help="A/B switch: load this build of libmofa_hip.so instead of the in-tree one "
                     "(same-box comparison of two kernel builds; the path is echoed in config.library)")
     args = ap.parse_args()
@@ -495,6 +499,9 @@ def main():
         _ops.GN_STATS = bool(args.gn_stats)
     if args.graph_steps >= 0:
         pipe.graph_steps = bool(args.graph_steps)
+    if args.ff_fused >= 0:
+        from mofa_video_amd import ops as _ops
+        _ops.FF_FUSED = bool(args.ff_fused)
     for _ in range(args.warmup):
         run_config(pipe, inp, cfg)
     # Roofline leg: HIP events around every implicit-GEMM / attention / softsplat launch of the LAST clip of the timed region
@@ -549,7 +556,7 @@ def main():
                 break
             except Exception:  # noqa: BLE001
                 pass
-        roofline = dict(kernel="igemm_f16_kernel", bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS,
+        roofline = dict(kernel="igemm_f16_kernel (+ ff320_kernel: the level-0 feed-forward GEMM pairs, fused with their LayerNorm / GELU / residuals)", bound="mfma", achieved=round(ach, 1), peak=MFMA_PEAK_TFLOPS,
                         unit="TFLOP/s", frac=round(ach / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                         launches_per_clip=ig["launches"],
                         timed_with_events="the last of the K timed clips, run in single-stream order (exclusive kernel durations)",
@@ -609,6 +616,7 @@ def main():
                                    "adapter trunk || UNet encoder, then the decoder's two CFG halves, on two HIP streams; the last timed clip (HIP "
                                    "events) single-stream"),
                        "graph_steps": bool(pipe.graph_steps), **({"gn_stats": bool(args.gn_stats)} if args.gn_stats >= 0 else {}),
+                       **({"ff_fused": bool(args.ff_fused)} if args.ff_fused >= 0 else {}),
                        "clip_ms": clip_ms,
                        "output_finite": finite, "comm_paths": comm_paths, **({"library": args.lib} if args.lib else {}),
                        "effective_tflops_per_gpu_reference_work_model": round(CLIP_TFLOPS[cfg] * clips / dt / world, 1)},

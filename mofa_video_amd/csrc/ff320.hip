@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
         // GELU micro-operations of pair d (hidden registers 2 d, 2 d + 1 of p[P ^ 1]): x * Phi(x), Phi as in gelu_phi_f (common.h);
         // FF_GOPS = 15 per pair on float2 (hipcc emits scalar v_fma_f32 pairs for them, which is what is wanted: packed fp32 measured
         // SLOWER beside the MFMAs, profiles/r06_ff320_anatomy.log), FF_ILP pairs alternating.
-        // The P^T tiles live in VGPRs, written by MFMAs issued through asm (mfma_p below): hipcc keeps every accumulator of a
+        // The P^T tiles live in VGPRs, written by MFMAs issued through asm (below): hipcc keeps every accumulator of a
         // 512-register kernel in the AGPR half, and v_accvgpr_read executes IN the matrix pipe, in order with the MFMAs -- 32 reads
         // per step cost 56 % of the kernel (1413 -> 599 us with the GELU fed from ordinary registers, same log).
         // HAZARD the compiler cannot see (the producer is an asm statement): an MFMA result may be read by a VALU instruction only
@@ -191,11 +191,9 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
                 hf[P ^ 1][d >> 2][2 * (d & 3) + 1] = (f16)Q[d][1];
             }
         };
-        // A's MFMA with the accumulator in VGPRs (see above).  Operands: af comes from a ds_read and c's first value from a global
-        // load (hipcc's own s_waitcnt cover both); xf was written by VALU long before; the same accumulator chains with 0 wait states.
-        auto mfma_p = [](f32x16& c, const f16x8& av, const f16x8& bv) __attribute__((always_inline)) {
-            asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
-        };
+        // A's MFMAs are issued through asm with the accumulators in VGPRs ("+v", see above).  Operands: the fragments come from
+        // ds_reads and the accumulators' first values from global loads (hipcc's own s_waitcnt cover both); xf was written by VALU
+        // long before; the same accumulator chains with 0 wait states.
         // this wave's pieces of the step: W2's five FIRST (needed at the next barrier: vmcnt counts in issue order), then W1's ten
         auto dma_piece = [&](auto pcc) __attribute__((always_inline)) {
             constexpr int pc = decltype(pcc)::v, n2 = D2 ? 5 : 0;
@@ -222,8 +220,11 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
                 O[i % FF_NJ] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, hf[P][i / FF_NJ], O[i % FF_NJ], 0, 0, 0);
             } else {
                 constexpr int t = i - NC;
-                if constexpr (t & 1) mfma_p(pg[P], af, xf[t >> 1]);
-                else mfma_p(pv[P], af, xf[t >> 1]);
+                // the value and the gate MFMA of a k-step as ONE asm statement: hipcc puts a (conservative) s_waitcnt in front of
+                // every asm statement that reads a freshly loaded fragment -- one per k-step instead of two (+ 1-2 % on the kernel)
+                if constexpr ((t & 1) == 0)
+                    asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %4, %0\n\tv_mfma_f32_32x32x16_f16 %1, %3, %4, %1"
+                                 : "+v"(pv[P]), "+v"(pg[P]) : "v"(af), "v"(ring[(i + 1) % FF_RING]), "v"(xf[t >> 1]));
             }
             constexpr int ib = i < FF_BDELAY ? 0 : i - FF_BDELAY;
             constexpr int m0 = (ib * NOPS) / (NS - FF_BDELAY), m1 = i < FF_BDELAY ? 0 : ((ib + 1) * NOPS) / (NS - FF_BDELAY);

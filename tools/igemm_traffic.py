@@ -14,7 +14,7 @@ def rows(name):
 
 
 def total(rs, counter, col="counter_sum"):
-    return sum(float(r[col]) for r in rs if "igemm" in r["kernel"] and "fixup" not in r["kernel"] and "tile_stats" not in r["kernel"] and r["counter"] == counter)
+    return sum(float(r[col]) for r in rs if ("igemm" in r["kernel"] or "ff320" in r["kernel"]) and "fixup" not in r["kernel"] and "tile_stats" not in r["kernel"] and r["counter"] == counter)
 
 
 f, w, m = rows("FETCH_SIZE"), rows("WRITE_SIZE"), rows("mfma")
@@ -24,7 +24,7 @@ fetch_kb, write_kb = total(f, "FETCH_SIZE"), total(w, "WRITE_SIZE")
 hbm = (2 * fetch_kb + write_kb) * 1024
 busy, gui = total(m, "SQ_VALU_MFMA_BUSY_CYCLES"), total(m, "GRBM_GUI_ACTIVE")
 out = {
-    "kernel": "igemm_f16_kernel (all tile / epilogue instantiations)",
+    "kernel": "igemm_f16_kernel (all tile / epilogue instantiations) + ff320_kernel (the fused level-0 feed-forward: the two GEMMs of 21 layers per step)",
     "launches": launches,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes, "
               "tools/profile_round.sh) on tools/profile_step.py 1 (one full-size denoise step + one 8-frame VAE chunk)",

@@ -43,11 +43,11 @@ class LoopbackComm:
                 buf[j * slot_rows:(j + 1) * slot_rows].copy_(buf[i * slot_rows:(i + 1) * slot_rows])
         return _Done()
 
-    def gather_small_into(self, buf, slot_rows, ranks):
+    def gather_small_into(self, buf, slot_rows, ranks, lane=0):
         self.all_gather_into(buf, slot_rows, ranks)
         return buf
 
-    def halo_begin(self, first, last, prev_rank, next_rank, ranks):
+    def halo_begin(self, first, last, prev_rank, next_rank, ranks, lane=0):
         return _HaloWork([], last.clone() if prev_rank is not None else None, first.clone() if next_rank is not None else None)
 
 
