@@ -234,6 +234,31 @@ typedef struct mofa_ff320_args {
 int mofa_ff320_f16(const mofa_ff320_args* a, mofa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Linear layers on 320-channel tokens (level 0), transposed form, optional LayerNorm in front:
+ *   out[m, n] = f16( f16( s_acc * (W[n, :] . xhat[m] + bias[n] + rowvec[idx(m), n]) ) + s1 * r1[m, n] ),     n < N, N % 64 == 0
+ *   xhat[m] = norm ? LayerNorm_eps(x[m]) without affine part (the norm's gain / bias are folded into W / bias) : x[m]
+ *   idx(m) = ((m / rv_div) * rv_mul + (m % rv_mod_in)) % rv_mod_out          (as mofa_igemm_f16; rowvec row idx at rowvec + idx * N)
+ * i.e. norm1 -> to_q | to_k | to_v (N = 960), to_out.0 + attn2's vector + residual, proj_in of diffusers' BasicTransformerBlock /
+ * TemporalBasicTransformerBlock / TransformerSpatioTemporalModel at 320 channels (built at
+ * models/unet_spatio_temporal_condition_controlnet.py:169-232, models/controlnet_sdv.py:259-309); replaces mofa_layernorm_f16 +
+ * mofa_igemm_f16 for them.  wp: fp16 [N / 64 chunks][2 tiles][20 k-steps][64 lanes][8]: element e of lane l =
+ * W'[64 c + 32 t + (l & 31)][16 s + 8 (l >> 5) + e], W' = W * LayerNorm gain (mofa_video_amd/weights.py::pack_lin320);
+ * bias fp32 [N] (+ W . LayerNorm bias) or NULL.  Pointers 16-byte aligned, ld* % 8 == 0. */
+typedef struct mofa_lin320_args {
+    const void* x;          /* fp16 [M][ldx], 320 channels                      */
+    const void* wp;         /* packed, see above                                */
+    const float* bias;      /* fp32 [N] or NULL                                 */
+    const float* rowvec;    /* fp32 rows of N or NULL                           */
+    const void* r1;         /* fp16 [M][ldr1] or NULL                           */
+    void* out;              /* fp16 [M][ldo]                                    */
+    int32_t M, N, ldx, ldo, ldr1, norm;
+    int32_t rv_div, rv_mul, rv_mod_in, rv_mod_out;
+    float eps, s_acc, s1;
+    int32_t reserved[3];    /* must be 0; sizeof(mofa_lin320_args) = 112         */
+} mofa_lin320_args;
+int mofa_lin320_f16(const mofa_lin320_args* a, mofa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Element-wise / data movement
  * ---------------------------------------------------------------------------------------- */
 /* y = a*x + b*y on contiguous fp32 vectors (latent window accumulation / averaging of the Keypoint loop,

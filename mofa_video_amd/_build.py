@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmofa_hip.so")
 PROBE_LIB = os.path.join(HERE, "..", "tools", "libmofa_hip_probe.so")
-SOURCES = ["igemm.hip", "igemm8.hip", "igemm320.hip", "ff320.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip",
+SOURCES = ["igemm.hip", "igemm8.hip", "igemm320.hip", "ff320.hip", "lin320.hip", "attention.hip", "norm.hip", "elementwise.hip", "softsplat.hip", "output.hip",
            "cmp_ops.hip", "frontend.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "igemm_common.h"), os.path.join(CSRC, "igemm_pipe.h"),
            os.path.join(HERE, "..", "include", "mofa_hip.h")]

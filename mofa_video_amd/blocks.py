@@ -20,7 +20,7 @@ import torch
 
 from . import lib as L
 from . import ops
-from .weights import (f32, interleave_geglu, pack_conv3d_t3, pack_conv3x3, pack_ff320, pack_linear, pad_rows)
+from .weights import (f32, interleave_geglu, pack_conv3d_t3, pack_conv3x3, pack_ff320, pack_lin320, pack_linear, pad_rows)
 
 BIG = 1 << 30
 
@@ -332,7 +332,7 @@ class CrossAttnVec:
 
 
 class SelfAttn:
-    def __init__(self, s, heads, fold_q_scale=False):
+    def __init__(self, s, heads, fold_q_scale=False, norm=None, norm_eps=1e-5):
         """fold_q_scale: multiply the Q projection by head_dim^-0.5 * log2(e) at load time (fp32, rounded to fp16 once,
         each weight independently -- the effect on Q averages over the C input channels and is far below Q's own fp16
         rounding), so the spatial attention kernel takes Q as is (``ops.attn_spatial(prescaled=True)``)."""
@@ -347,6 +347,25 @@ class SelfAttn:
         w = torch.cat([wq, s.get("to_k.weight"), s.get("to_v.weight")], 0)
         self.wqkv = s.dev(pack_linear(w))
         self.to_out = Linear(s.sub("to_out.0"))
+        # level 0 (C = 320), spatial block: LayerNorm + the three projections as ONE launch (ops.lin320 with the norm's gain / bias
+        # folded in): 491 against 555 us for mofa_layernorm_f16 + mofa_igemm_f16 at 460 800 tokens, 58 against 71 at a rank-of-8's
+        # 64 512.  The kernel's other uses measured SLOWER than the 256x320 implicit-GEMM tile and are not wired: plain q | k | v 427
+        # against 403 us, to_out + vector + residual 278 against 216, proj_in 180 against 154 (profiles/r06_lin320.log)
+        self.qkv_pk = None
+        if norm is not None and self.C == 320:
+            wp, bp = pack_lin320(w, None, norm.get("weight"), norm.get("bias"))
+            self.qkv_pk = (s.dev(wp), s.dev(bp), norm_eps)
+
+    def qkv_normed(self, x):
+        """q, k, v of LayerNorm(x) from the un-normalised tokens (level 0, one launch)"""
+        wp, bp, eps = self.qkv_pk
+        qkv = ops.lin320(x, wp, bp, norm=True, eps=eps)
+        Cc = self.C
+        return qkv[:, :Cc], qkv[:, Cc:2 * Cc], qkv[:, 2 * Cc:]
+
+    @property
+    def can_fuse_norm(self):
+        return self.qkv_pk is not None and ops.LIN320
 
     def qkv(self, x):
         qkv = ops.igemm(x, self.wqkv)
@@ -374,7 +393,7 @@ class TransformerSpatioTemporal:
         self.proj_in, self.proj_out = Linear(s.sub("proj_in")), Linear(s.sub("proj_out"))
         b = s.sub("transformer_blocks.0")
         self.norm1, self.norm3 = LayerNorm(b.sub("norm1")), LayerNorm(b.sub("norm3"))
-        self.attn1, self.attn2, self.ff = (SelfAttn(b.sub("attn1"), heads, fold_q_scale=True), CrossAttnVec(b.sub("attn2")),
+        self.attn1, self.attn2, self.ff = (SelfAttn(b.sub("attn1"), heads, fold_q_scale=True, norm=b.sub("norm1")), CrossAttnVec(b.sub("attn2")),
                                            GegluFF(b.sub("ff"), norm=b.sub("norm3")))
         t = s.sub("temporal_transformer_blocks.0")
         self.norm_in, self.tnorm1, self.tnorm3 = LayerNorm(t.sub("norm_in")), LayerNorm(t.sub("norm1")), LayerNorm(t.sub("norm3"))
@@ -401,7 +420,7 @@ class TransformerSpatioTemporal:
         h = self.norm(x, N, HW)
         h = self.proj_in(h)
         # --- spatial BasicTransformerBlock ---
-        q, k, v = self.attn1.qkv(self.norm1(h))
+        q, k, v = self.attn1.qkv_normed(h) if self.attn1.can_fuse_norm else self.attn1.qkv(self.norm1(h))
         a = ops.attn_spatial(q, k, v, N, self.heads, HW, head_dim=self.attn1.head_dim, prescaled=self.attn1.q_prescaled)
         h = self.attn1.to_out(a, r1=h, s1=1.0, rowvec=v_sp, rv=(T * HW, 1, 1, BIG))      # + attn1 + attn2
         # level 0 (C = 320): norm + feed-forward + residual(s) as one launch (GegluFF.fused); ff_in's launch also writes

@@ -50,6 +50,16 @@ class Ff320Args(C.Structure):
     ]
 
 
+class Lin320Args(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("wp", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("r1", C.c_void_p), ("out", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("ldx", C.c_int32), ("ldo", C.c_int32), ("ldr1", C.c_int32), ("norm", C.c_int32),
+        ("rv_div", C.c_int32), ("rv_mul", C.c_int32), ("rv_mod_in", C.c_int32), ("rv_mod_out", C.c_int32),
+        ("eps", C.c_float), ("s_acc", C.c_float), ("s1", C.c_float),
+        ("reserved", C.c_int32 * 3),
+    ]
+
+
 _P, _I, _F, _L = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 # name -> argtypes (every symbol include/mofa_hip.h declares; tests check they all resolve)
@@ -57,7 +67,8 @@ PROTOTYPES = {
     "mofa_version": [],
     "mofa_igemm_f16": [_P, _P],                     # (const mofa_igemm_args*: a byref(IgemmArgs) or the packed 192 bytes)
     "mofa_igemm_stats_ok": [_P],
-    "mofa_ff320_f16": [_P, _P],                     # (const mofa_ff320_args*: the packed 152 bytes)
+    "mofa_ff320_f16": [_P, _P],
+    "mofa_lin320_f16": [_P, _P],                    # (const mofa_lin320_args*: the packed 112 bytes)                     # (const mofa_ff320_args*: the packed 152 bytes)
     "mofa_attn_spatial_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P],
     "mofa_attn_spatial_qb_f16": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P],
     "mofa_transpose_v_f16": [_P, _P, _I, _I, _I, _I, _P],

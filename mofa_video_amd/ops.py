@@ -359,6 +359,42 @@ def ff320(x, w1p, b1, w2p, b2, eps=1e-5, pos=None, HW=1, T=1, r2=None, s_acc=1.0
     return out if ln_out is None else (out, yl)
 
 
+_LIN320_ARGS = struct.Struct("@6P10i3f3i")
+assert _LIN320_ARGS.size == C.sizeof(L.Lin320Args)
+LIN320 = True            # A/B switch: False = mofa_layernorm_f16 + mofa_igemm_f16 for every 320-channel projection (blocks.Linear320)
+
+
+def lin320(x, wp, bias=None, norm=False, eps=1e-5, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, s_acc=1.0, out=None):
+    """out = f16(f16(s_acc * (W . xhat + bias + rowvec[idx(m)])) + s1 * r1), xhat = LayerNorm(x) without affine part if ``norm`` (the
+    norm's gain / bias folded into the packed operands, weights.pack_lin320) else x; N = 64 * wp.shape[0].  mofa_lin320_f16."""
+    lib = L.load()
+    _chk(x, F16)
+    M, N = x.shape[0], wp.shape[0] * 64
+    assert x.shape[1] == 320 and wp.dtype is F16 and wp.numel() == N * 320
+    if out is None:
+        out = torch.empty((M, N), dtype=F16, device=x.device)
+    else:
+        assert out.dtype is F16 and out.shape[0] == M and out.shape[1] >= N
+        _written(out)
+    if bias is not None:
+        assert bias.dtype is F32 and bias.numel() == N
+    if rowvec is not None:
+        assert rowvec.dtype is F32 and rowvec.dim() == 2 and rowvec.shape[1] == N and rowvec.stride(1) == 1
+        assert rowvec.is_contiguous() or (rowvec.stride(0) % N == 0 and rv[1] == rowvec.stride(0) // N), (rowvec.stride(), N, rv)
+    if r1 is not None:
+        assert r1.dtype is F16 and r1.shape[0] == M and r1.shape[1] >= N
+    args = _LIN320_ARGS.pack(x.data_ptr(), wp.data_ptr(), L.ptr(bias) or 0, L.ptr(rowvec) or 0, L.ptr(r1) or 0, out.data_ptr(),
+                             M, N, _ld(x), _ld(out), _ld(r1) if r1 is not None else 0, 1 if norm else 0,
+                             rv[0], rv[1], rv[2], rv[3], eps, s_acc, s1, 0, 0, 0)
+    t0 = TIMER.start() if TIMER is not None else None
+    rc = lib.mofa_lin320_f16(args, L.stream_ptr())
+    if rc != 0:
+        L.check(rc, "mofa_lin320_f16")
+    if t0 is not None:                                        # counted with the implicit GEMMs it replaces (roofline leg of bench.py)
+        TIMER.stop("igemm_f16_kernel", t0, flops=2.0 * M * N * 320, tag=(10, 0, 0, M, N, 320, 0))
+    return out
+
+
 # ---- attention -----------------------------------------------------------------------------------------
 Q_FOLD_LOG2E = 1.4426950408889634
 

@@ -66,9 +66,9 @@ def pack_ff320(w1, b1, w2, gamma, beta):
     W1 . (g * xhat + b) + b1 = (W1 * g) . xhat + (W1 . b + b1); weights are rounded to fp16 once, afterwards.
     Returns (w1p fp16 [40, 2, 20, 64, 8], b1 fp32 [2560], w2p fp16 [40, 10, 2, 64, 8])."""
     C, H = 320, 1280
-    w1, w2 = w1.detach().float().reshape(2 * H, C), w2.detach().float().reshape(C, H)
-    gamma, beta = gamma.detach().float(), beta.detach().float()
-    b1f = (b1.detach().float() if b1 is not None else torch.zeros(2 * H)) + w1 @ beta
+    w1, w2 = w1.detach().float().cpu().reshape(2 * H, C), w2.detach().float().cpu().reshape(C, H)   # (packed on the host)
+    gamma, beta = gamma.detach().float().cpu(), beta.detach().float().cpu()
+    b1f = (b1.detach().float().cpu() if b1 is not None else torch.zeros(2 * H)) + w1 @ beta
     w1g = (w1 * gamma[None, :]).to(torch.float16)
     lane = torch.arange(64)
     n, lh = lane % 32, lane // 32
@@ -84,6 +84,28 @@ def pack_ff320(w1, b1, w2, gamma, beta):
              (jj & 3)[None, None, None, None, :] + 8 * (jj >> 2)[None, None, None, None, :])
     w2p = w2.to(torch.float16)[rows2.expand(40, 10, 2, 64, 8), cols2.expand(40, 10, 2, 64, 8)].contiguous()
     return w1p, b1f.contiguous(), w2p
+
+
+def pack_lin320(w, b=None, gamma=None, beta=None):
+    """Operands of ``mofa_lin320_f16`` (csrc/lin320.hip; layout in include/mofa_hip.h) from an nn.Linear weight [N, 320] (N % 64 == 0)
+    and, when a LayerNorm precedes it, the norm's weight / bias, folded in fp32: W (g xhat + beta) + b = (W g) xhat + (W beta + b).
+    Returns (wp fp16 [N / 64, 2, 20, 64, 8], bias fp32 [N] or None)."""
+    w = w.detach().float().cpu().reshape(w.shape[0], -1)          # (packed on the host whatever device the checkpoint tensors are on)
+    N, K = w.shape
+    assert K == 320 and N % 64 == 0, (N, K)
+    bias = b.detach().float().cpu().clone() if b is not None else None
+    if beta is not None:
+        bias = (bias if bias is not None else torch.zeros(N)) + w @ beta.detach().float().cpu()
+    if gamma is not None:
+        w = w * gamma.detach().float().cpu()[None, :]
+    wh = w.to(torch.float16)
+    lane = torch.arange(64)
+    n, lh = lane % 32, lane // 32
+    c, t, s_, e = torch.arange(N // 64), torch.arange(2), torch.arange(20), torch.arange(8)
+    rows = 64 * c[:, None, None, None, None] + 32 * t[None, :, None, None, None] + n[None, None, None, :, None]
+    cols = 16 * s_[None, None, :, None, None] + 8 * lh[None, None, None, :, None] + e[None, None, None, None, :]
+    shp = (N // 64, 2, 20, 64, 8)
+    return wh[rows.expand(shp), cols.expand(shp)].contiguous(), (bias.contiguous() if bias is not None else None)
 
 
 def f32(t):

@@ -151,6 +151,47 @@ def ff320(x, w1p, b1, w2p, b2, eps=1e-5, pos=None, HW=1, T=1, r2=None, s_acc=1.0
     return y, yl
 
 
+def unpack_lin320(wp):
+    """inverse of weights.pack_lin320 from the layout include/mofa_hip.h documents for mofa_lin320_f16: -> W' fp16 [N, 320]"""
+    key = ("lin", wp.data_ptr())
+    if key not in _UNPACKED:
+        nch = wp.shape[0]
+        p = wp.reshape(nch, 2, 20, 64, 8).cpu()
+        w = torch.zeros(nch * 64, 320, dtype=F16)
+        for l in range(64):
+            n, lh = l & 31, l >> 5
+            for t in range(2):
+                rows = 64 * torch.arange(nch) + 32 * t + n
+                cols = (16 * torch.arange(20)[:, None] + 8 * lh + torch.arange(8)[None, :]).reshape(-1)
+                w[rows[:, None], cols[None, :]] = p[:, t, :, l, :].reshape(nch, 160)
+        _UNPACKED[key] = (w, wp)
+    return _UNPACKED[key][0]
+
+
+def lin320(x, wp, bias=None, norm=False, eps=1e-5, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, s_acc=1.0, out=None):
+    w = unpack_lin320(wp)
+    N, M = w.shape[0], x.shape[0]
+    xf = x[:, :320].float()
+    if norm:
+        xf = F.layer_norm(xf, (320,), None, None, eps).to(F16).float()
+    y = xf @ w.float().T
+    if bias is not None:
+        y = y + bias.float()
+    if rowvec is not None:
+        m = torch.arange(M)
+        idx = ((m // rv[0]) * rv[1] + (m % rv[2])) % rv[3]
+        rows = torch.as_strided(rowvec, (int(idx.max()) + 1, N), (N, 1))
+        y = y + rows.float()[idx]
+    y = (s_acc * y).to(F16).float()
+    if r1 is not None:
+        y = y + s1 * r1[:, :N].float()
+    y = y.to(F16)
+    if out is not None:
+        out[:, :N].copy_(y)
+        return out
+    return y
+
+
 def group_norm(x, gamma, beta, nframes, HW, eps, frames_per_stat=1, silu=False, out=None, C_=None):
     C = gamma.numel()
     fps = frames_per_stat
@@ -315,7 +356,7 @@ def resize_nearest_f32(x, h, w):
     return torch.nn.functional.interpolate(x[None].float(), size=(h, w), mode="nearest")[0]
 
 
-NAMES = ["attn_temporal", "timestep_embedding", "silu_f32", "axpby_", "axpby_out", "copy2d", "gn_nparts", "gn_partial_into", "gn_apply_gathered", "resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "ff320", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
+NAMES = ["attn_temporal", "timestep_embedding", "silu_f32", "axpby_", "axpby_out", "copy2d", "gn_nparts", "gn_partial_into", "gn_apply_gathered", "resize_nearest_f32", "axpby_f32_", "cast_f16_to_f32", "cast_f32_to_f16", "igemm", "ff320", "lin320", "layer_norm", "group_norm", "attn_spatial", "transpose_v", "softmax_rows_", "nchw_to_tokens",
          "tokens_to_nchw", "patchify", "filter1d_reflect", "resize_bicubic_ac"]
 
 

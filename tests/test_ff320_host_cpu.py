@@ -26,6 +26,19 @@ def test_pack_ff320_matches_documented_layout():
     assert torch.allclose(b1f, b1 + w1 @ beta, atol=1e-4)
 
 
+def test_pack_lin320_matches_documented_layout():
+    from mofa_video_amd.weights import pack_lin320
+    g = torch.Generator().manual_seed(4)
+    w, b = torch.randn(960, 320, generator=g), torch.randn(960, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(320, generator=g), 0.3 * torch.randn(320, generator=g)
+    wp, bp = pack_lin320(w, b, gamma, beta)
+    assert wp.dtype == torch.float16 and tuple(wp.shape) == (15, 2, 20, 64, 8)
+    assert torch.equal(emu_ops.unpack_lin320(wp), (w * gamma[None]).half())
+    assert torch.allclose(bp, b + w @ beta, atol=1e-4)
+    wp2, bp2 = pack_lin320(w[:320])
+    assert bp2 is None and torch.equal(emu_ops.unpack_lin320(wp2), w[:320].half())
+
+
 def test_transformer_block_fused_ff_equals_unfused(monkeypatch):
     """C = 320 transformer layer: level-0 feed-forwards fused (three ops.ff320 calls) against LayerNorm + two GEMMs each"""
     from mofa_video_amd import blocks, ops, schema
@@ -44,6 +57,7 @@ def test_transformer_block_fused_ff_equals_unfused(monkeypatch):
     monkeypatch.setattr(ops, "ff320", lambda *a, **k: (calls.append(sorted(k)), real(*a, **k))[1])
     for fused in (True, False):
         monkeypatch.setattr(ops, "FF_FUSED", fused)
+        monkeypatch.setattr(ops, "LIN320", fused)                   # (the 320-channel projections with their norms folded, too)
         c = blocks.Ctx(B, T)
         c.ctx16 = (torch.randn(B, 128, generator=torch.Generator().manual_seed(3))).half()
         outs.append(xf(x, c, H, W).float())
