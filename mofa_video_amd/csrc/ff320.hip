@@ -255,37 +255,50 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
         const f16* xrow = xg + (size_t)mr * a.ldx;
         const float* prow = nullptr;
         if constexpr (POS) prow = a.pos + (size_t)((mr / a.HW) % a.T) * FF_C;
-        // ---- token row -> registers, LayerNorm in fp32 (two passes over registers; gain / bias live in W1 / b1) ----
+        // ---- token row -> registers, LayerNorm in fp32: three passes over the fp16 fragments (mean, centred squares, normalise), x' =
+        //      x + pos re-formed in each (pos rows are L1 hits) -- no fp32 copy of the row (160 registers that made hipcc spill).
+        //      Gain / bias of the norm live in W1 / b1. ----
         {
 #pragma unroll
             for (int s = 0; s < FF_KS; ++s) xf[s] = *(const f16x8*)(xrow + 16 * s + 8 * lh);
-            float xs[FF_KS * 8];
-            float sum = 0.f;
-#pragma unroll
-            for (int s = 0; s < FF_KS; ++s) {
-                f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+            auto xval = [&](int s, int e, const f32x4& p0, const f32x4& p1) __attribute__((always_inline)) -> float {
+                return (float)xf[s][e] + (POS ? (e < 4 ? p0[e & 3] : p1[e & 3]) : 0.f);
+            };
+            auto pos_of = [&](int s, f32x4& p0, f32x4& p1) __attribute__((always_inline)) {
                 if constexpr (POS) {
                     p0 = *(const f32x4*)(prow + 16 * s + 8 * lh);
                     p1 = *(const f32x4*)(prow + 16 * s + 8 * lh + 4);
                 }
+            };
+            float sum = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float v = (float)xf[s][e] + (e < 4 ? p0[e & 3] : p1[e & 3]);
-                    xs[8 * s + e] = v;
-                    sum += v;
-                }
+            for (int s = 0; s < FF_KS; ++s) {
+                f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+                pos_of(s, p0, p1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sum += xval(s, e, p0, p1);
             }
             sum += __shfl_xor(sum, 32, 64);
             const float mean = sum * (1.0f / FF_C);
             float sq = 0.f;
 #pragma unroll
-            for (int i = 0; i < FF_KS * 8; ++i) { const float d = xs[i] - mean; sq = fmaf(d, d, sq); }
+            for (int s = 0; s < FF_KS; ++s) {
+                f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+                pos_of(s, p0, p1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = xval(s, e, p0, p1) - mean; sq = fmaf(d, d, sq); }
+            }
             sq += __shfl_xor(sq, 32, 64);
             const float rstd = rsqrtf(sq * (1.0f / FF_C) + a.eps);
 #pragma unroll
-            for (int s = 0; s < FF_KS; ++s)
+            for (int s = 0; s < FF_KS; ++s) {
+                f32x4 p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0;
+                pos_of(s, p0, p1);
+                f16x8 y;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) xf[s][e] = (f16)((xs[8 * s + e] - mean) * rstd);
+                for (int e = 0; e < 8; ++e) y[e] = (f16)((xval(s, e, p0, p1) - mean) * rstd);
+                xf[s] = y;
+            }
         }
         // ---- O^T starts at b2: register r of tile j <-> out col 32 j + 8 (r >> 2) + 4 lh + (r & 3) ----
 #pragma unroll

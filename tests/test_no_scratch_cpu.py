@@ -48,3 +48,19 @@ def test_hot_kernels_use_no_scratch():
                 bad.append((src, name, r))
     assert seen >= 37
     assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not found")
+def test_fused_level0_kernels_shipped_variants():
+    """round 6: the fused feed-forward's three instantiations the transformer blocks launch (spatial ff; ff_in with the position vector
+    and the LayerNorm output; temporal ff with the AlphaBlender residual) use no scratch at all; the transposed linear kernel's one
+    shipped instantiation (LayerNorm + q | k | v) spills a few pointers at TILE boundaries (outside its chunk loop; <= 8 registers).
+    The other instantiations exist for the C ABI's generality and the parity tests only."""
+    ff, ln = _usage("ff320.hip"), _usage("lin320.hip")
+    shipped = {"ILb0ELb0ELb0E": 0, "ILb1ELb0ELb1E": 0, "ILb0ELb1ELb0E": 0}
+    for tag, limit in shipped.items():
+        rows = [r for n, r in ff.items() if "ff320_kernel" + tag in n]
+        assert len(rows) == 1, (tag, list(ff))
+        assert rows[0].get("VGPRs Spill", 0) <= limit and rows[0].get("ScratchSize", 0) == 0, (tag, rows[0])
+    rows = [r for n, r in ln.items() if "lin320_kernelILb1ELb0ELb0E" in n]
+    assert len(rows) == 1 and rows[0].get("VGPRs Spill", 0) <= 8, rows

@@ -58,6 +58,18 @@ def test_default_output_is_pil_and_pil_condition_is_accepted(tiny):
     assert torch.isfinite(d).all() and tuple(d.shape) == tuple(b.shape)
 
 
+def test_call_under_inference_mode_equals_no_grad(tiny):
+    """round-5 advice: a caller who wraps ``pipe(...)`` in ``torch.inference_mode()`` (tensors without a version counter) crashed on the
+    first GroupNorm-producer convolution.  The whole call runs there and gives the bits of the ordinary (``no_grad``) call."""
+    from mofa_video_amd.pipeline import FlowControlNetPipeline
+    mods, _, inp = tiny
+    pipe = FlowControlNetPipeline(**mods)
+    a = _call(pipe, inp, output_type="pt").frames
+    with torch.inference_mode():
+        b = _call(pipe, inp, output_type="pt").frames
+    assert torch.equal(a[0], b[0])
+
+
 def test_callback_on_step_end_and_fp16_rounding_switch(tiny):
     from mofa_video_amd.pipeline import FlowControlNetPipeline
     mods, _, inp = tiny
