@@ -56,7 +56,8 @@ def test_fused_level0_kernels_shipped_variants():
     and the LayerNorm output; temporal ff with the AlphaBlender residual) use no scratch at all; the transposed linear kernel's one
     shipped instantiation (LayerNorm + q | k | v) spills a few pointers at TILE boundaries (outside its chunk loop; <= 8 registers).
     The other instantiations exist for the C ABI's generality and the parity tests only."""
-    ff, ln = _usage("ff320.hip"), _usage("lin320.hip")
+    with ThreadPoolExecutor(2) as ex:
+        ff, ln = ex.map(_usage, ["ff320.hip", "lin320.hip"])
     shipped = {"ILb0ELb0ELb0E": 0, "ILb1ELb0ELb1E": 0, "ILb0ELb1ELb0E": 0}
     for tag, limit in shipped.items():
         rows = [r for n, r in ff.items() if "ff320_kernel" + tag in n]
