@@ -45,6 +45,12 @@ template <int V> struct IC { static constexpr int v = V; };
 #ifndef FF_ILP
 #define FF_ILP 2                               // GELU pairs (2 hidden columns each) whose micro-operations alternate
 #endif
+#ifndef FF_LOOK_D
+#define FF_LOOK_D 6                            // MFMA slots a weight fragment is read ahead of its use (even)
+#endif
+#ifndef FF_BDELAY_D
+#define FF_BDELAY_D 3                          // MFMA slots into a step before the GELU reads the previous step's tiles
+#endif
 // compile-time loop: f(IC<0>{}), f(IC<1>{}), ... -- the slot schedule below needs every index as a constant expression
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
     f32x16 O[FF_NJ];
     f32x16 pv[2], pg[2];
     f16x8 hf[2][2];
-    constexpr int FF_LOOK = 6, FF_BDELAY = 3, FF_GOPS = 15;
+    constexpr int FF_LOOK = FF_LOOK_D, FF_BDELAY = FF_BDELAY_D, FF_GOPS = 15;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto step = [&](auto do_a, auto do_b, auto do_c, auto par, const int chunk_a, const int slot_a, auto d1, const int chunk_w1,
                     const int slot_w1, auto d2, const int chunk_w2) __attribute__((always_inline)) {
