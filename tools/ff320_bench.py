@@ -68,7 +68,10 @@ def main():
                 print(f"  {name:28s} fused {tf:8.1f} us (min {tfm:8.1f}) = {flop / tf / 1e6:7.1f} TF/s   [{os.path.basename(args.lib) or 'in-tree'}]")
                 continue
             tu, tum = timeit(un)
-            e = ((fu()[0] if isinstance(fu(), tuple) else fu()).float() - (un() if "norm1" not in name else ff(norm(x, rowvec=pos, rv_div=HW, rv_mod=T), r1=x, s1=1.0, rowvec=pos, rv=(HW, 1, 1, T))).float()).norm().item()
+            a_ = fu()
+            if isinstance(a_, tuple):                              # (out, LayerNorm(out)): compare the LayerNorm outputs, as the unfused row returns
+                a_ = a_[1]
+            e = (a_.float() - un().float()).norm().item()
             print(f"  {name:28s} fused {tf:8.1f} us (min {tfm:8.1f}) = {flop / tf / 1e6:7.1f} TF/s | unfused {tu:8.1f} us (min {tum:8.1f}) = "
                   f"{flop / tu / 1e6:7.1f} TF/s | x{tu / tf:.3f}   (diff norm {e:.3e})")
 
