@@ -29,7 +29,7 @@ def _close(got, ref, what, tol=2e-3):
 
 @pytest.mark.parametrize("N", [320, 960, 64])
 @pytest.mark.parametrize("kind", ["plain", "norm", "bias+r1", "norm+bias", "rv+r1", "rv quirk+r1", "all"])
-@pytest.mark.parametrize("M", [256 * 3, 256 * 260 + 77, 33])
+@pytest.mark.parametrize("M", [256 * 3, 256 * 260 + 77, 33, 256 * 355 + 5, 256 * 456])   # (last three: left-over round split 1 chunk / 8 chunks / whole tiles per item)
 def test_lin320_vs_fp32_reference(ops, N, kind, M):
     from mofa_video_amd.weights import pack_lin320
     if M > 60000 and (N != 320 or kind not in ("all", "plain")):
