@@ -274,11 +274,46 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #else
                     const float p = __builtin_amdgcn_exp2f(s[b][ts][r]);   // raw v_exp_f32
 #endif
-#ifndef ATT_T_NOSUM
+#if !defined(ATT_T_NOSUM) && !defined(ATT_SUM_MFMA4) && !defined(ATT_SUM_DOT2)
                     psum += p;
 #endif
                     pf[b][ts][r >> 3][r & 7] = (f16)p;
                 }
+#ifdef ATT_SUM_DOT2
+            // (experiment) v_dot2_f32_f16 against (1, 1): 16 instead of 32 instructions, fp32 accumulation of the fp16 probabilities
+            {
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 one2 = {(f16)1.f, (f16)1.f};
+#pragma unroll
+                for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const h2 pp = {pf[b][ts][u][2 * e], pf[b][ts][u][2 * e + 1]};
+                            psum = __builtin_amdgcn_fdot2(pp, one2, psum, false);
+                        }
+            }
+#endif
+#ifdef ATT_SUM_MFMA4
+            // (experiment, tools/attn_sum_experiment.sh) the lane's 32 probabilities summed by eight v_mfma_f32_4x4x4_16B_f16 with an all-ones
+            // A operand: every lane of a 4-lane block gets the sum of ITS OWN four fp16 values in all four result registers
+            {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                const h4 ones = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+                f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ts = 0; ts < 2; ++ts)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const h4 lo = {pf[b][ts][u][0], pf[b][ts][u][1], pf[b][ts][u][2], pf[b][ts][u][3]};
+                        const h4 hi = {pf[b][ts][u][4], pf[b][ts][u][5], pf[b][ts][u][6], pf[b][ts][u][7]};
+                        t4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, lo, t4, 0, 0, 0);
+                        t4 = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, hi, t4, 0, 0, 0);
+                    }
+                psum = t4[0];
+            }
+#endif
             const float ptot = psum + __shfl_xor(psum, 32, 64);           // both key halves of the query row
             const bool move = !(ptot < ATT_DEFER_SUM) || t == 0;           // (NaN-safe; tile 0: m_run = 0 is no reference yet)
             if (__any(move)) {
