@@ -47,6 +47,22 @@ def test_argument_validation_without_gpu():
     assert l.mofa_softsplat_ws_bytes(24, 72, 128) > 24 * 72 * 128 * 44
 
 
+def test_every_entry_point_rejects_null_arguments_without_gpu():
+    """each of the header's compute entry points, called with NULL pointers and zero sizes, returns MOFA_EINVAL before any
+    device call (there is no GPU in this container: a launch attempt would return MOFA_ELAUNCH or crash instead)"""
+    from mofa_video_amd import lib
+    l = lib.load()
+    query = {"mofa_version", "mofa_gn_nparts", "mofa_softsplat_ws_bytes", "mofa_flow_to_image_ws_bytes", "mofa_igemm_stats_ok"}
+    checked = 0
+    for name, argtypes in lib.PROTOTYPES.items():
+        if name in query:
+            continue
+        args = [None if t is ctypes.c_void_p else (0.0 if t in (ctypes.c_float, ctypes.c_double) else 0) for t in argtypes]
+        assert getattr(l, name)(*args) == -22, name
+        checked += 1
+    assert checked == len(lib.PROTOTYPES) - len(query) and checked >= 50
+
+
 def test_product_does_not_import_oracle_or_reference():
     pkg = os.path.join(ROOT, "mofa_video_amd")
     for dp, _, files in os.walk(pkg):
