@@ -63,6 +63,35 @@ def test_every_entry_point_rejects_null_arguments_without_gpu():
     assert checked == len(lib.PROTOTYPES) - len(query) and checked >= 50
 
 
+def test_fused_level0_entry_points_validate_layout_without_gpu():
+    """mofa_ff320_f16 / mofa_lin320_f16 (include/mofa_hip.h): struct sizes as documented, and every layout rule of the header is
+    checked before the launch -- one violated rule at a time on otherwise valid (never dereferenced) addresses"""
+    from mofa_video_amd import lib
+    l = lib.load()
+    assert ctypes.sizeof(lib.Ff320Args) == 152 and ctypes.sizeof(lib.Lin320Args) == 112
+    A = 0x10000                                                     # 16-byte aligned, never touched: validation fails first
+
+    def ff(**kw):
+        a = lib.Ff320Args(x=A, w1p=A, b1=A, w2p=A, b2=A, out=A, M=256, ldx=320, ldo=320, eps=1e-5, s_acc=1.0)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return l.mofa_ff320_f16(ctypes.byref(a), None)
+    for bad in (dict(M=0), dict(ldx=312), dict(ldx=324), dict(ldo=316), dict(x=A + 8), dict(out=A + 2), dict(w1p=A + 4), dict(b2=A + 4),
+                dict(w2p=None), dict(pos=A), dict(pos=A, HW=64), dict(pos=A + 4, HW=64, T=4), dict(r2=A, ldr2=0), dict(r2=A + 8, ldr2=320),
+                dict(out_ln=A, ldoln=320), dict(out_ln=A, ln_gamma=A, ln_beta=A, ldoln=300), dict(out_ln=A, ln_gamma=A + 4, ln_beta=A, ldoln=320)):
+        assert ff(**bad) == -22, bad
+
+    def lin(**kw):
+        a = lib.Lin320Args(x=A, wp=A, out=A, M=256, N=320, ldx=320, ldo=320, s_acc=1.0)
+        for k, v in kw.items():
+            setattr(a, k, v)
+        return l.mofa_lin320_f16(ctypes.byref(a), None)
+    for bad in (dict(M=0), dict(N=0), dict(N=96), dict(N=330), dict(ldx=312), dict(ldo=256), dict(N=960), dict(x=A + 8), dict(wp=A + 2),
+                dict(bias=A + 4), dict(rowvec=A), dict(rowvec=A + 4, rv_div=1, rv_mod_in=1, rv_mod_out=1), dict(r1=A, ldr1=0),
+                dict(r1=A + 8, ldr1=320), dict(r1=A, ldr1=324)):
+        assert lin(**bad) == -22, bad
+
+
 def test_product_does_not_import_oracle_or_reference():
     pkg = os.path.join(ROOT, "mofa_video_amd")
     for dp, _, files in os.walk(pkg):
