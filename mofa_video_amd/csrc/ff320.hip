@@ -61,6 +61,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // step barrier: this wave's LDS-DMA pieces up to the N youngest have landed (vmcnt counts in issue order), its fragment reads are
 // back, then everybody is here.  N = the W1 pieces of the chunk two steps ahead, which may stay in flight across the barrier.
+#ifdef FF_T_NOB1
+constexpr int FF_PRE = 0;
+#else
+constexpr int FF_PRE = 8;                      // b1 loads of the next step, issued at the end of a step (see step())
+#endif
 template <int N>
 __device__ __forceinline__ void ff_barrier() {
 #if defined(FF_DBG_VM0)
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
     constexpr int FF_LOOK = FF_LOOK_D, FF_BDELAY = FF_BDELAY_D, FF_GOPS = 15;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     auto step = [&](auto do_a, auto do_b, auto do_c, auto par, const int chunk_a, const int slot_a, auto d1, const int chunk_w1,
-                    const int slot_w1, auto d2, const int chunk_w2) __attribute__((always_inline)) {
+                    const int slot_w1, auto d2, const int chunk_w2, auto own_b1, auto pre_b1) __attribute__((always_inline)) {
         constexpr bool A = decltype(do_a)::v != 0, B = decltype(do_b)::v != 0, Cc = decltype(do_c)::v != 0;
         // DMA W1(chunk_w1) -> W1 slot slot_w1, W2(chunk_w2) -> W2 slot P ^ 1; A reads W1 slot slot_a
         constexpr bool D1 = decltype(d1)::v != 0, D2 = decltype(d2)::v != 0;
@@ -136,15 +141,25 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
         char* dst1 = smem_ff + OFF_W1 + slot_w1 * W1_SLOT + wave * 10240;
         char* dst2 = smem_ff + OFF_W2 + (P ^ 1) * W2_SLOT + wave * 5120;
         const int src1 = chunk_w1 * W1_SLOT + wave * 10240, src2 = chunk_w2 * W2_SLOT + wave * 5120;
-        if constexpr (A) {
+        // b1 = the first value of A's accumulators, by global loads (the LDS is all weight ring).  A step loads the b1 of the NEXT
+        // step's chunk at its END (pre_b1: the registers p[P ^ 1] are free once its GELU has read them), in front of the barrier:
+        // loaded at the start of their own step they had 20 MFMA slots to arrive and hipcc's wait in front of A's first MFMA stalled
+        // on them (- 3.5...4.8 % of the launch without the loads, profiles/r06_ff320_anatomy.log); only a tile's step 0 loads its own.
+        auto load_b1 = [&](auto pc, const int chunk) __attribute__((always_inline)) {
+            constexpr int PP = decltype(pc)::v;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 bv = *(const f32x4*)(b1l + 32 * chunk_a + 8 * q);
-                const f32x4 bg = *(const f32x4*)(b1l + FF_H + 32 * chunk_a + 8 * q);
+#ifdef FF_T_NOB1                               // timing-only: no bias loads at all
+                const f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {1.f, 1.f, 1.f, 1.f};
+#else
+                const f32x4 bv = *(const f32x4*)(b1l + 32 * chunk + 8 * q);
+                const f32x4 bg = *(const f32x4*)(b1l + FF_H + 32 * chunk + 8 * q);
+#endif
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { pv[P][4 * q + e] = bv[e]; pg[P][4 * q + e] = bg[e]; }
+                for (int e = 0; e < 4; ++e) { pv[PP][4 * q + e] = bv[e]; pg[PP][4 * q + e] = bg[e]; }
             }
-        }
+        };
+        if constexpr (A && decltype(own_b1)::v != 0) load_b1(IC<P>{}, chunk_a);
         // slot i < NC: C's MFMA on O[i % 10] with k-step u = i / 10 (dependent MFMAs ten slots apart), block 2 j + u of the W2
         // slot; slot NC + t: A's MFMA (k-step t / 2, value / gate tile t % 2), block (t % 2) * 20 + t / 2 of the W1 slot
         auto frag = [&](int i) __attribute__((always_inline)) -> f16x8 {
@@ -244,6 +259,7 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
         });
         // (a step with few slots cannot place all its DMA pieces: the rest go here)
         static_for<(NS + 1) / 2, NPIECE>([&](auto pcc) __attribute__((always_inline)) { dma_piece(pcc); });
+        if constexpr (decltype(pre_b1)::v != 0) load_b1(IC<P ^ 1>{}, chunk_a + 1);
     };
 
     const f16* xg = (const f16*)a.x;
@@ -323,24 +339,25 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
         //      (vmcnt(10)): W2(k - 1) and everything older has landed, W1(k + 2) stays in flight for another step -- an L2 -> LDS
         //      piece takes longer to land than the 60 MFMAs of a step leave.  42 = 0 mod 3 and mod 2: steps 40 / 41 fetch the NEXT
         //      tile's W1(0) / W1(1) into slots 0 / 1, where its steps 0 / 1 read them. ----
+        // (barrier counts: + 8 for the b1 loads the step before issued last -- they stay in flight across the barrier)
         ff_barrier<0>();                                           // step 0: A(0); W1(2) -> slot 2
-        step(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, 0, 0, IC<1>{}, 2, 2, IC<0>{}, 0);
-        ff_barrier<10>();                                          // step 1: A(1) || B(0); W2(0) -> slot 0, W1(3) -> slot 0
-        step(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}, 1, 1, IC<1>{}, 3, 0, IC<1>{}, 0);
+        step(IC<1>{}, IC<0>{}, IC<0>{}, IC<0>{}, 0, 0, IC<1>{}, 2, 2, IC<0>{}, 0, IC<1>{}, IC<1>{});
+        ff_barrier<10 + FF_PRE>();                                 // step 1: A(1) || B(0); W2(0) -> slot 0, W1(3) -> slot 0
+        step(IC<1>{}, IC<1>{}, IC<0>{}, IC<1>{}, 1, 1, IC<1>{}, 3, 0, IC<1>{}, 0, IC<0>{}, IC<1>{});
         int sa = 2;                                                // k % 3 of the even step below
         for (int k = 2; k < FF_NCHUNK - 2; k += 2) {
             const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
-            ff_barrier<10>();                                      // step k (even)
-            step(IC<1>{}, IC<1>{}, IC<1>{}, IC<0>{}, k, sa, IC<1>{}, k + 2, sa1 == 2 ? 0 : sa1 + 1, IC<1>{}, k - 1);
-            ff_barrier<10>();                                      // step k + 1 (odd)
-            step(IC<1>{}, IC<1>{}, IC<1>{}, IC<1>{}, k + 1, sa1, IC<1>{}, k + 3 < FF_NCHUNK ? k + 3 : 0, sa, IC<1>{}, k);
+            ff_barrier<10 + FF_PRE>();                             // step k (even)
+            step(IC<1>{}, IC<1>{}, IC<1>{}, IC<0>{}, k, sa, IC<1>{}, k + 2, sa1 == 2 ? 0 : sa1 + 1, IC<1>{}, k - 1, IC<0>{}, IC<1>{});
+            ff_barrier<10 + FF_PRE>();                             // step k + 1 (odd)
+            step(IC<1>{}, IC<1>{}, IC<1>{}, IC<1>{}, k + 1, sa1, IC<1>{}, k + 3 < FF_NCHUNK ? k + 3 : 0, sa, IC<1>{}, k, IC<0>{}, IC<1>{});
             sa = sa2;
         }
         // k = 38 (38 % 3 = 2), 39 (0): no chunk 40 / 41 exists, nothing for W1 to fetch
-        ff_barrier<10>();
-        step(IC<1>{}, IC<1>{}, IC<1>{}, IC<0>{}, 38, 2, IC<0>{}, 0, 0, IC<1>{}, 37);
-        ff_barrier<0>();
-        step(IC<1>{}, IC<1>{}, IC<1>{}, IC<1>{}, 39, 0, IC<0>{}, 0, 0, IC<1>{}, 38);
+        ff_barrier<10 + FF_PRE>();
+        step(IC<1>{}, IC<1>{}, IC<1>{}, IC<0>{}, 38, 2, IC<0>{}, 0, 0, IC<1>{}, 37, IC<0>{}, IC<1>{});
+        ff_barrier<FF_PRE>();
+        step(IC<1>{}, IC<1>{}, IC<1>{}, IC<1>{}, 39, 0, IC<0>{}, 0, 0, IC<1>{}, 38, IC<0>{}, IC<0>{});
         // the raw token row once more (its registers held the normalised row until A(39)): the residual of the epilogue, landing
         // under the two drain steps; the AlphaBlender's second residual likewise
         f16x8 rr[R2 ? FF_KS : 1];
@@ -351,9 +368,9 @@ __global__ __launch_bounds__(256, 1) void ff320_kernel(const mofa_ff320_args a, 
             if constexpr (R2) rr[s] = *(const f16x8*)(r2row + 16 * s + 8 * lh);
         }
         ff_barrier<R2 ? 40 : 20>();                                // step 40: C(38) || B(39); W2(39) -> slot 1; W1(next tile's 0) -> slot 0
-        step(IC<0>{}, IC<1>{}, IC<1>{}, IC<0>{}, 0, 0, IC<1>{}, 0, 0, IC<1>{}, FF_NCHUNK - 1);
+        step(IC<0>{}, IC<1>{}, IC<1>{}, IC<0>{}, 0, 0, IC<1>{}, 0, 0, IC<1>{}, FF_NCHUNK - 1, IC<0>{}, IC<0>{});
         ff_barrier<10>();                                          // step 41: C(39); W1(next tile's 1) -> slot 1
-        step(IC<0>{}, IC<0>{}, IC<1>{}, IC<1>{}, 0, 0, IC<1>{}, 1, 1, IC<0>{}, 0);
+        step(IC<0>{}, IC<0>{}, IC<1>{}, IC<1>{}, 0, 0, IC<1>{}, 1, 1, IC<0>{}, 0, IC<0>{}, IC<0>{});
         // ---- epilogue: out = f16( f16(s_acc * O) + s1 * x' + s2 * r2 ), x' = x (+ pos).  All 20 pieces (8 columns each) are formed
         //      first and stored under ONE row test: a branch per piece would serialise the loads behind vmcnt(0) waits ----
         f16* orow = og + (size_t)mr * a.ldo;
