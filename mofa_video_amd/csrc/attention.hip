@@ -34,6 +34,9 @@ __device__ __forceinline__ f16x4 lds_read_tr4(const f16* p) {
     return __builtin_bit_cast(f16x4, v);
 }
 
+#ifndef ATT_NBUF_D
+#define ATT_NBUF_D 2   // (3: K / V tiles fetched two ahead -- bit-identical, measured 1-2 % slower, profiles/r06_attn_anatomy.log)
+#endif
 template <int D, int QB>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ q, const f16* __restrict__ k,
                                                               const f16* __restrict__ v, f16* __restrict__ out,
@@ -46,14 +49,18 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     // swapped in rows with bit 1 set (the 4 key rows x 64 bytes of a transpose read then cover 4 distinct bank quarters).
     // D = 128 (0.1 % of a clip) keeps the register-staged, padded form.
     constexpr bool DMA = D == 64;
+    // DMA form: ATT_NBUF_D = 2 buffers, tile t + 1 fetched while tile t is computed.  (-DATT_NBUF_D=3: a ring of three, fetched TWO
+    // tiles ahead with a counted end-of-tile wait -- the landing time of a piece is NOT what the end-of-tile wait stalls on: same
+    // results bit for bit, 1-2 % slower at S = 9216 and 2304, profiles/r06_attn_anatomy.log)
+    constexpr int NBUF = DMA ? ATT_NBUF_D : 2;
     constexpr int ATT_KSTR = DMA ? D : D + 8;
     constexpr int ATT_VSTR = DMA ? D : D + 32; // V tile row stride (halves)
     constexpr int KK = D / 16;       // MFMA k-steps of S^T
     constexpr int DB = D / 32;       // 32-wide output d-blocks
     constexpr int NCH = D / 32;      // 16-byte chunks per thread per tile (K and V each)
     extern __shared__ __attribute__((aligned(16))) char smem_att[];
-    f16* sKb = (f16*)smem_att;                          // [2][64 * ATT_KSTR]
-    f16* sVb = sKb + 2 * ATT_TILE * ATT_KSTR;           // [2][64 * ATT_VSTR]
+    f16* sKb = (f16*)smem_att;                          // [NBUF][64 * ATT_KSTR]
+    f16* sVb = sKb + NBUF * ATT_TILE * ATT_KSTR;        // [NBUF][64 * ATT_VSTR]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -191,7 +198,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     const int ntiles = (S + ATT_TILE - 1) / ATT_TILE;
     if constexpr (DMA) {
         dma_tile(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NBUF == 3 && ntiles > 1) {
+            dma_tile(1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // tile 0 has landed; tile 1's four pieces stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     } else {
         load_tile(0);
         store_tile(0);
@@ -203,15 +215,17 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #pragma unroll
     for (int kk = 0; kk < KK; ++kk) kstale[kk] = *(const f16x8*)(sKb + l31 * ATT_KSTR + kk * 16 + lh * 8);
 #endif
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
+    int buf = 0;                                                    // t % NBUF
+    for (int t = 0; t < ntiles; ++t, buf = (buf + 1 == NBUF ? 0 : buf + 1)) {
         const int k0 = t * ATT_TILE;
-        if (t + 1 < ntiles) {
 #ifndef ATT_T_NODMA
+        if constexpr (DMA && NBUF == 3) {
+            if (t + 2 < ntiles) dma_tile(t + 2, buf == 0 ? 2 : buf - 1);   // slot (t + 2) % 3 = (t - 1) % 3: released by the last barrier
+        } else if (t + 1 < ntiles) {
             if constexpr (DMA) dma_tile(t + 1, buf ^ 1);            // (the other buffer was released by the last barrier)
             else load_tile(k0 + ATT_TILE);
-#endif
         }
+#endif
 
         // ---- S^T tiles: s[b][ts][r] = score(key = k0 + 32*ts + (r&3) + 8*(r>>2) + 4*lh, query = 32*b + l31) ----
         // the accumulators start at -m_run: NEGM keeps that as a 16-register tuple per query block (it changes only when the
@@ -370,7 +384,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                 }
         }
         if (t + 1 < ntiles) {
-            if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of tile t + 1 have landed
+            // this wave's pieces of tile t + 1 have landed (the loop has no other vector-memory operation: with the ring of three,
+            // the four pieces of tile t + 2 -- the youngest -- may stay in flight)
+            if constexpr (DMA && NBUF == 3) {
+                if (t + 2 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else store_tile(buf ^ 1);
         }
 #ifndef ATT_T_NOBAR
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 template <int D, int QB>
 static int launch_attn_spatial(const void* q, const void* k, const void* v, void* out, int nframes, int heads, int S,
                                int ldq, int ldk, int ldv, int ldo, float c, hipStream_t st) {
-    constexpr int LDS = D == 64 ? 2 * (ATT_TILE * D + ATT_TILE * D) * 2 : 2 * (ATT_TILE * (D + 8) + ATT_TILE * (D + 32)) * 2;
+    constexpr int LDS = D == 64 ? ATT_NBUF_D * (ATT_TILE * D + ATT_TILE * D) * 2 : 2 * (ATT_TILE * (D + 8) + ATT_TILE * (D + 32)) * 2;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)attn_spatial_kernel<D, QB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
