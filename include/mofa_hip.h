@@ -243,7 +243,9 @@ int mofa_ff320_f16(const mofa_ff320_args* a, mofa_stream_t stream);
  * models/unet_spatio_temporal_condition_controlnet.py:169-232, models/controlnet_sdv.py:259-309); replaces mofa_layernorm_f16 +
  * mofa_igemm_f16 for them.  wp: fp16 [N / 64 chunks][2 tiles][20 k-steps][64 lanes][8]: element e of lane l =
  * W'[64 c + 32 t + (l & 31)][16 s + 8 (l >> 5) + e], W' = W * LayerNorm gain (mofa_video_amd/weights.py::pack_lin320);
- * bias fp32 [N] (+ W . LayerNorm bias) or NULL.  Pointers 16-byte aligned, ld* % 8 == 0. */
+ * bias fp32 [N] (+ W . LayerNorm bias) or NULL.  Pointers 16-byte aligned, ld* % 8 == 0.  The output is addressed through a 32-bit
+ * buffer descriptor (rows beyond M are dropped by its bounds check): (M + 256) * ldo * 2 bytes must stay below 4 GB, MOFA_EINVAL
+ * otherwise (the caller then uses mofa_layernorm_f16 + mofa_igemm_f16: mofa_video_amd/ops.py::lin320_fits). */
 typedef struct mofa_lin320_args {
     const void* x;          /* fp16 [M][ldx], 320 channels                      */
     const void* wp;         /* packed, see above                                */

@@ -420,7 +420,8 @@ class TransformerSpatioTemporal:
         h = self.norm(x, N, HW)
         h = self.proj_in(h)
         # --- spatial BasicTransformerBlock ---
-        q, k, v = self.attn1.qkv_normed(h) if self.attn1.can_fuse_norm else self.attn1.qkv(self.norm1(h))
+        fuse_qkv = self.attn1.can_fuse_norm and ops.lin320_fits(h.shape[0], 3 * self.C)
+        q, k, v = self.attn1.qkv_normed(h) if fuse_qkv else self.attn1.qkv(self.norm1(h))
         a = ops.attn_spatial(q, k, v, N, self.heads, HW, head_dim=self.attn1.head_dim, prescaled=self.attn1.q_prescaled)
         h = self.attn1.to_out(a, r1=h, s1=1.0, rowvec=v_sp, rv=(T * HW, 1, 1, BIG))      # + attn1 + attn2
         # level 0 (C = 320): norm + feed-forward + residual(s) as one launch (GegluFF.fused); ff_in's launch also writes

@@ -364,6 +364,12 @@ assert _LIN320_ARGS.size == C.sizeof(L.Lin320Args)
 LIN320 = True            # A/B switch: False = mofa_layernorm_f16 + mofa_igemm_f16 for every 320-channel projection (blocks.Linear320)
 
 
+def lin320_fits(M, ldo):
+    """mofa_lin320_f16 addresses its output through a 32-bit buffer descriptor: (M + 256) rows of ldo halves must stay below 4 GB
+    (include/mofa_hip.h); longer token lists take the LayerNorm + implicit-GEMM launches"""
+    return (M + 256) * ldo * 2 < 0xFFFFFFFF
+
+
 def lin320(x, wp, bias=None, norm=False, eps=1e-5, rowvec=None, rv=(1, 1, 1, 1 << 30), r1=None, s1=1.0, s_acc=1.0, out=None):
     """out = f16(f16(s_acc * (W . xhat + bias + rowvec[idx(m)])) + s1 * r1), xhat = LayerNorm(x) without affine part if ``norm`` (the
     norm's gain / bias folded into the packed operands, weights.pack_lin320) else x; N = 64 * wp.shape[0].  mofa_lin320_f16."""

@@ -88,8 +88,11 @@ def test_fused_level0_entry_points_validate_layout_without_gpu():
         return l.mofa_lin320_f16(ctypes.byref(a), None)
     for bad in (dict(M=0), dict(N=0), dict(N=96), dict(N=330), dict(ldx=312), dict(ldo=256), dict(N=960), dict(x=A + 8), dict(wp=A + 2),
                 dict(bias=A + 4), dict(rowvec=A), dict(rowvec=A + 4, rv_div=1, rv_mod_in=1, rv_mod_out=1), dict(r1=A, ldr1=0),
-                dict(r1=A + 8, ldr1=320), dict(r1=A, ldr1=324)):
+                dict(r1=A + 8, ldr1=320), dict(r1=A, ldr1=324),
+                dict(M=1 << 22, N=960, ldo=960)):                      # (M + 256) * ldo * 2 bytes beyond the 32-bit output descriptor
         assert lin(**bad) == -22, bad
+    from mofa_video_amd import ops
+    assert ops.lin320_fits(460800, 960) and ops.lin320_fits(2 * 97 * 9216, 960) and not ops.lin320_fits(1 << 22, 960)
 
 
 def test_product_does_not_import_oracle_or_reference():
